@@ -1,0 +1,93 @@
+"""ctypes binding of libpcc_hip.so (include/pcc.h).
+
+This is the only place the package touches native code.  There is no CPU
+fallback: if the shared library is missing or a GPU entry point fails, the
+error propagates (RuntimeError / PccError) — a product path that silently ran
+elsewhere would void every parity claim.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpcc_hip.so")
+
+PCC_OK = 0
+PCC_E_ARG, PCC_E_HIP, PCC_E_RANGE, PCC_E_DUP, PCC_E_STREAM, PCC_E_NOMEM = -1, -2, -3, -4, -5, -6
+
+
+class PccError(RuntimeError):
+    def __init__(self, code, where, text):
+        super().__init__(f"{where} failed ({code}): {text}")
+        self.code = code
+
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+pi64, pi32, pf32 = C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); every symbol declared in include/pcc.h
+PROTOTYPES = {
+    "pcc_abi_version": (i32, []),
+    "pcc_last_error": (C.c_char_p, []),
+    "pcc_create": (vp, [i32, vp]),
+    "pcc_destroy": (None, [vp]),
+    "pcc_set_stream": (i32, [vp, vp]),
+    "pcc_sync": (i32, [vp]),
+    "pcc_timer_start": (i32, [vp]),
+    "pcc_timer_stop": (i32, [vp]),
+    "pcc_timer_elapsed_ms": (i32, [vp, pf32]),
+    "pcc_morton_keys": (i32, [vp, vp, i64, vp, vp]),
+    "pcc_keys_to_coords": (i32, [vp, vp, i64, vp]),
+    "pcc_linear_keys": (i32, [vp, vp, i64, vp]),
+    "pcc_sort_pairs": (i32, [vp, vp, vp, i64, i32]),
+    "pcc_sort_coords": (i32, [vp, vp, i64, vp]),
+    "pcc_gather_rows": (i32, [vp, vp, vp, i64, i32, vp]),
+    "pcc_check_unique": (i32, [vp, vp, i64, pi32]),
+    "pcc_batch_offsets": (i32, [vp, vp, i64, i32, pi64]),
+    "pcc_down_coords": (i32, [vp, vp, i64, i32, vp, vp, i64, pi64]),
+    "pcc_up_coords": (i32, [vp, vp, i64, i32, vp]),
+    "pcc_build_map": (i32, [vp, vp, i64, i32, vp]),
+    "pcc_lookup": (i32, [vp, vp, i64, vp, i64, vp]),
+    "pcc_gather_rows_or_zero": (i32, [vp, vp, vp, i64, i32, vp]),
+    "pcc_sparse_conv": (i32, [vp, vp, i64, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp]),
+    "pcc_convT_gen": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, vp]),
+    "pcc_linear": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, vp]),
+    "pcc_topk_prune": (i32, [vp, vp, i64, i32, pi64, pi64, vp, pi64]),
+    "pcc_factorized_quant": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "pcc_factorized_dequant": (i32, [vp, vp, i64, i32, vp, vp]),
+    "pcc_gaussian_quant": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp]),
+    "pcc_gaussian_indexes": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
+    "pcc_gaussian_dequant": (i32, [vp, vp, vp, i64, i32, vp, f32, f32, f32, vp]),
+    "pcc_rans_encode": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i64, pi64]),
+    "pcc_rans_decode": (i32, [vp, i64, vp, i64, vp, i32, vp, vp, i32, vp]),
+    "pcc_rans_encode_multi": (i32, [vp, vp, i64, i32, vp, i32, vp, vp, i32, vp, i64, pi64]),
+    "pcc_octree_levels": (i32, [vp, vp, i64, i32, i32, vp, i64, pi64]),
+    "pcc_octree_pack": (i32, [vp, pi64, i32, i64, pi32, vp, i64, pi64]),
+    "pcc_octree_peek": (i32, [vp, i64, pi64, pi32, pi32]),
+    "pcc_octree_unpack": (i32, [vp, i64, vp, i64]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpcc_hip.so once; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C demo-learned-point-cloud-compression_amd/csrc`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.pcc_abi_version() != 1:
+            raise RuntimeError("libpcc_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code, where):
+    if code != PCC_OK:
+        raise PccError(code, where, lib().pcc_last_error().decode(errors="replace"))

@@ -1,0 +1,188 @@
+"""DecompressionPipeline — drop-in for the reference's decoder operator
+(receiver/decoder/codec_parallel.py:18-502; caller receiver/decoder/decoder.py:44,62).
+
+`decompress(bytes) -> (list of {"points","colors"} per frame, sideinfo)` with
+the reference's sideinfo keys (including the spelling "guassian_model") and
+stage taxonomy D1..D6.  All stage work runs in libpcc_hip.so on the MI355X.
+"""
+import queue
+import struct
+import time
+
+import numpy as np
+import torch
+
+from . import runtime as _rt
+from . import utils
+from .model import ColorModel
+from .sparse import SparseTensor
+
+
+class DecompressionPipeline:
+    def __init__(self, device=0, slots=3, output="numpy"):
+        self.device = torch.device("cuda", device)
+        base_path = "./unified/results/"
+        self.decompression_model = self.load_model(base_path)
+        self.output = output                  # "numpy" (reference behaviour) or "device"
+        self._slots = queue.Queue()
+        for _ in range(slots):
+            self._slots.put(_rt.Runtime(device))
+
+    def load_model(self, base_path):
+        model_name = "demo_small"
+        decompression_model = ColorModel({"name": model_name})
+        decompression_model.load_state_dict(None)
+        decompression_model.to(self.device)
+        decompression_model.update()
+        decompression_model.eval()
+        return decompression_model
+
+    # ------------------------------------------------------------------ main
+    def decompress(self, compressed_data):
+        """bitstream reading -> reconstruction (codec_parallel.py:141-171)"""
+        t_start = time.time()
+        rt = self._slots.get()
+        try:
+            with rt:
+                y_strings, z_strings, y_shapes, z_shapes, points_streams, ks, q, t_1 = \
+                    self.read_bitstream_batched(compressed_data)
+                y_points, t_2 = self.geometry_decompression_step(points_streams)
+                z_hats, t_3 = self.factorized_model_step_batched(z_strings, z_shapes, y_points)
+                gaussian_params, t_4 = self.hyper_synthesis_step(z_hats)
+                y_hat, t_5 = self.gaussian_model_step_batched(y_strings, y_shapes, y_points, q, gaussian_params)
+                reconstructed_pointcloud, t_6 = self.hyper_synthesis(y_hat, ks)
+                final_data, t_7 = self.pack_batches(reconstructed_pointcloud, len(points_streams))
+        finally:
+            self._slots.put(rt)
+        sideinfo = {"time_measurements": {}, "timestamps": {}}
+        sideinfo["time_measurements"]["bitstream_reading"] = t_1
+        sideinfo["time_measurements"]["geometry_decompression"] = t_2
+        sideinfo["time_measurements"]["factorized_model"] = t_3
+        sideinfo["time_measurements"]["hyper_synthesis"] = t_4
+        sideinfo["time_measurements"]["guassian_model"] = t_5
+        sideinfo["time_measurements"]["synthesis_transform"] = t_6
+        sideinfo["timestamps"]["codec_start"] = t_start
+        sideinfo["timestamps"]["codec_end"] = time.time()
+        return final_data, sideinfo
+
+    # ------------------------------------------------------------------ stages
+    def read_bitstream_batched(self, compressed_data):
+        """Step 1: parse the container (codec_parallel.py:173-216)"""
+        t0 = time.time()
+        buf = memoryview(compressed_data)
+        pos = 0
+
+        def take(fmt):
+            nonlocal pos
+            size = struct.calcsize(fmt)
+            if pos + size > len(buf):
+                raise _rt.PccError(-5, "read_bitstream_batched", "truncated container")
+            vals = struct.unpack_from(fmt, buf, pos)
+            pos += size
+            return vals
+
+        def take_bytes(n):
+            nonlocal pos
+            if n < 0 or pos + n > len(buf):
+                raise _rt.PccError(-5, "read_bitstream_batched", "truncated container")
+            b = bytes(buf[pos:pos + n])
+            pos += n
+            return b
+
+        num_frames, q_g, q_a = take(">idd")
+        q = [q_g, q_a]
+        y_shapes, z_shapes, y_len, z_len = take(">iiii")
+        y_strings = [take_bytes(y_len)]
+        z_strings = [take_bytes(z_len)]
+        points_streams, ks = [], [[], [], []]
+        for _ in range(num_frames):
+            p_len, k1, k2, k3 = take(">iiii")
+            ks[0].append(k1)
+            ks[1].append(k2)
+            ks[2].append(k3)
+            points_streams.append(take_bytes(p_len))
+        return y_strings, z_strings, y_shapes, z_shapes, points_streams, ks, q, time.time() - t0
+
+    def geometry_decompression_step(self, points_streams):
+        """Step 2: latent coordinates of every frame (codec_parallel.py:266-289)"""
+        t0 = time.time()
+        y_points = [utils.gpcc_decode(s, 8) for s in points_streams]
+        y_points = utils.stack_tensors(y_points)
+        return y_points, time.time() - t0
+
+    def factorized_model_step_batched(self, z_strings, z_shapes, y_points):
+        """Step 3: re-derive the z coordinates from the y coordinates with two
+        stride-2 maps, decode z (codec_parallel.py:291-318)"""
+        t0 = time.time()
+        rt = _rt.current()
+        n_frames = int(y_points[:, 0].max().item()) + 1 if y_points.shape[0] else 0
+        latent_coordinates = SparseTensor(coordinates=y_points,
+                                          features=torch.ones((y_points.shape[0], 1)),
+                                          tensor_stride=8, device=self.device)
+        latent_coordinates.cs.set_batches(n_frames)
+        self._y_cs = latent_coordinates.cs
+        g_s = self.decompression_model.g_s
+        latent_coordinates = g_s.down_conv(latent_coordinates)
+        latent_coordinates = g_s.down_conv(latent_coordinates)
+        z_points = utils.sort_points(latent_coordinates.C)
+        if z_points.shape[0] != int(z_shapes):
+            raise _rt.PccError(-5, "factorized_model_step_batched",
+                               f"container says N_z={int(z_shapes)}, coordinates give {z_points.shape[0]}")
+        eb = self.decompression_model.entropy_model.entropy_bottleneck
+        z_hat_rows = eb.decompress_rows(rt, z_strings, int(z_shapes))
+        z_hat = SparseTensor(coordinates=z_points, features=z_hat_rows, tensor_stride=32, device=self.device)
+        return z_hat, time.time() - t0
+
+    def hyper_synthesis_step(self, z_hat):
+        """Step 4: hyper synthesis"""
+        t0 = time.time()
+        gaussian_params = self.decompression_model.entropy_model.h_s(z_hat)
+        gaussian_params.rt.sync()
+        return gaussian_params, time.time() - t0
+
+    def gaussian_model_step_batched(self, y_strings, y_shapes, y_points, q, gaussian_params):
+        """Step 5: decode y and de-quantise with offsets (codec_parallel.py:382-419)"""
+        t0 = time.time()
+        rt = _rt.current()
+        em = self.decompression_model.entropy_model
+        y_points = utils.sort_points(y_points)
+        if y_points.shape[0] != int(y_shapes):
+            raise _rt.PccError(-5, "gaussian_model_step_batched",
+                               f"container says N_y={int(y_shapes)}, geometry gives {y_points.shape[0]}")
+        gaussian_params_feats = gaussian_params.features_at_coordinates(y_points)
+        scale = em.scale_nn(np.asarray([q], dtype=np.float32)) + em.eps
+        scale_dev = rt.to_device(np.ascontiguousarray(scale, dtype=np.float32))
+        a, b = em.offsets_ab
+        y_hat_rows = em.gaussian_conditional.decompress_rows(rt, y_strings[0], gaussian_params_feats, scale_dev,
+                                                             a, b)
+        y_hat = SparseTensor(coordinates=y_points, features=y_hat_rows, tensor_stride=8, device=self.device)
+        y_hat.cs.set_batches(self._y_cs.n_batch)
+        return y_hat, time.time() - t0
+
+    def hyper_synthesis(self, y_hat, ks):
+        """Step 6: synthesis transform g_s with top-k pruning (named as in the
+        reference, codec_parallel.py:465-472)"""
+        t0 = time.time()
+        reconstructed_pointcloud = self.decompression_model.g_s(y_hat, k=ks)
+        reconstructed_pointcloud.rt.sync()
+        return reconstructed_pointcloud, time.time() - t0
+
+    def pack_batches(self, pointcloud, num_frames=None):
+        """Step 7: split per frame, NaN -> 0, clip colours to [0,1]
+        (codec_parallel.py:474-502)"""
+        t0 = time.time()
+        offs = pointcloud.cs.offsets
+        if self.output == "device":
+            coords, colors = pointcloud.C, pointcloud.F
+            batch = [{"points": coords[offs[i]:offs[i + 1], 1:], "colors": colors[offs[i]:offs[i + 1]]}
+                     for i in range(len(offs) - 1)]
+            return batch, time.time() - t0
+        points = pointcloud.C.cpu().numpy()
+        colors = pointcloud.F.cpu().numpy()
+        batch = []
+        for i in range(len(offs) - 1):
+            item_points = points[offs[i]:offs[i + 1], 1:]
+            item_colors = np.nan_to_num(colors[offs[i]:offs[i + 1]], nan=0.0)
+            item_colors = np.clip(item_colors * 255.0, 0, 255) / 255
+            batch.append({"points": item_points, "colors": item_colors})
+        return batch, time.time() - t0

@@ -1,0 +1,108 @@
+// common.h — shared host/device helpers for libpcc_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/pcc.h"
+
+#define PCC_WAVE 64
+
+void pcc_set_error(const char* fmt, ...);
+
+#define PCC_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      pcc_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call,             \
+                    hipGetErrorString(e_));                                  \
+      return PCC_E_HIP;                                                      \
+    }                                                                        \
+  } while (0)
+
+#define PCC_CHECK_LAUNCH() PCC_HIP(hipGetLastError())
+
+#define PCC_REQUIRE(cond, code, ...)                                         \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      pcc_set_error(__VA_ARGS__);                                            \
+      return (code);                                                         \
+    }                                                                        \
+  } while (0)
+
+#define PCC_TRY(expr)                                                        \
+  do {                                                                       \
+    int r_ = (expr);                                                         \
+    if (r_ != PCC_OK) return r_;                                             \
+  } while (0)
+
+struct pcc_ctx {
+  int device;
+  hipStream_t stream;
+  // bump arena for per-call scratch
+  char* arena;
+  size_t arena_cap;
+  size_t arena_off;
+  // small pinned host staging for count read-backs
+  void* pinned;
+  size_t pinned_cap;
+  hipEvent_t ev0, ev1;
+  bool ev_valid;
+};
+
+// Reset the arena at the start of an API call.
+static inline void pcc_arena_reset(pcc_ctx* c) { c->arena_off = 0; }
+// Make sure the arena can hold `bytes` in total for this call; may
+// synchronise + reallocate (only ever called before the first arena_alloc of
+// an API call, so no live scratch is lost).
+int pcc_arena_reserve(pcc_ctx* c, size_t bytes);
+// Bump-allocate (256-B aligned).  Returns nullptr if the reservation was too
+// small (a library bug, reported as PCC_E_NOMEM by callers).
+void* pcc_arena_alloc(pcc_ctx* c, size_t bytes);
+
+static inline size_t pcc_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- Morton helpers (host + device) ---------------------------------------
+// spread the low 16 bits of v so that bit i lands at bit 3i
+__host__ __device__ static inline uint64_t pcc_spread3(uint32_t v) {
+  uint64_t x = v & 0xFFFFu;
+  x = (x | (x << 16)) & 0x0000FF0000FFull;
+  x = (x | (x << 8)) & 0x00F00F00F00Full;
+  x = (x | (x << 4)) & 0x0C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x249249249249ull;
+  return x;
+}
+__host__ __device__ static inline uint32_t pcc_compact3(uint64_t x) {
+  x &= 0x249249249249ull;
+  x = (x | (x >> 2)) & 0x0C30C30C30C3ull;
+  x = (x | (x >> 4)) & 0x00F00F00F00Full;
+  x = (x | (x >> 8)) & 0x0000FF0000FFull;
+  x = (x | (x >> 16)) & 0xFFFFull;
+  return (uint32_t)x;
+}
+// key = b<<48 | x bits at 3i+2, y at 3i+1, z at 3i  (biased by 32768)
+__host__ __device__ static inline uint64_t pcc_morton(int b, int x, int y,
+                                                      int z) {
+  return ((uint64_t)(uint32_t)b << 48) |
+         (pcc_spread3((uint32_t)(x + 32768)) << 2) |
+         (pcc_spread3((uint32_t)(y + 32768)) << 1) |
+         pcc_spread3((uint32_t)(z + 32768));
+}
+__host__ __device__ static inline void pcc_unmorton(uint64_t key, int* b,
+                                                    int* x, int* y, int* z) {
+  *b = (int)(key >> 48);
+  *x = (int)pcc_compact3(key >> 2) - 32768;
+  *y = (int)pcc_compact3(key >> 1) - 32768;
+  *z = (int)pcc_compact3(key) - 32768;
+}
+
+static inline int pcc_ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// internal cross-file entry points
+int pcc_scan_exclusive_u32(pcc_ctx* ctx, const uint32_t* d_in, uint32_t* d_out,
+                           int64_t n, uint32_t* d_total /*nullable, device*/);
+size_t pcc_scan_scratch_bytes(int64_t n);

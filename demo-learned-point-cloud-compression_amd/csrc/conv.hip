@@ -1,0 +1,307 @@
+// conv.hip — sparse network layers: gather-convolution (3^3 stride 1 and 2^3
+// stride 2 share one out-stationary kernel), generative transposed
+// convolution, 1x1 linear.
+//
+// Replaces MinkowskiEngine's convolution / generative transposed convolution /
+// linear forward kernels executed inside model.g_a, model.g_s, h_a, h_s
+// (codec_pipeline.py:273,287,354; codec_parallel.py:302-303,376,469).
+//
+// Arithmetic contract (pcc.h): out = bias, then for k ascending over PRESENT
+// neighbours, ci ascending: out = fmaf(x, w, out).  v_mfma_f32_32x32x2_f32 is
+// bit-for-bit that chain (2 ci per instruction, k-ordered), so the MFMA kernel
+// and the scalar-fmaf kernel give identical bits, and both equal the C oracle.
+// No atomics: a wave owns 32 output rows (out-stationary), so results do not
+// depend on scheduling.  An offset whose neighbour is absent for all 32 rows of
+// the tile is skipped (wave-uniform ballot); rows are Morton-sorted, so a tile
+// is spatially compact and on surface data most of the 27 offsets are skipped.
+//
+// Tile per wave: 32 rows x COUT(32|64) columns, accumulators in registers
+// (16 | 32 VGPRs).  Neighbour rows are gathered with 16-B lane loads (8 lanes
+// per 128-B row, coalesced per row) into a wave-private LDS tile with pitch
+// CIN+1 floats, which makes both the ds_write_b32 pattern (bank = r + 4*chunk
+// + j) and the MFMA-operand ds_read_b32 pattern (bank = i + 2s + h)
+// conflict-free.  Weights W[k] (4-8 KB) are read straight from L1/L2 in the
+// B-operand layout (two coalesced 128-B rows per load).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+#define GC_WAVES 4
+
+template <int CIN, int NT>
+__global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma(
+    const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+    int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+    float* __restrict__ out) {
+  constexpr int COUT = NT * 32;
+  constexpr int PITCH = CIN + 1;
+  __shared__ float a_lds[GC_WAVES][32 * PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
+  if (row0 >= n_out) return;  // wave-uniform
+  const int i = lane & 31, h = lane >> 5;
+  float* a = a_lds[wave];
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float b = bias[t * 32 + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+  }
+
+  const bool row_ok = (row0 + i) < n_out;
+  for (int k = 0; k < k_vol; ++k) {
+    const int32_t nb = row_ok ? nbr[(int64_t)k * pitch + row0 + i] : -1;
+    if (__ballot(nb >= 0) == 0ull) continue;  // nobody in this tile has offset k
+
+    // ---- stage the gathered A tile (32 rows x CIN) into LDS
+    if constexpr (CIN == 32) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+        const int32_t src = __shfl(nb, r, 64);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src >= 0) v = *reinterpret_cast<const float4*>(in + (int64_t)src * CIN + chunk * 4);
+        float* d = a + r * PITCH + chunk * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    } else {
+      static_assert(CIN == 4, "CIN must be 4 or 32");
+      if (lane < 32) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nb >= 0) v = *reinterpret_cast<const float4*>(in + (int64_t)nb * CIN);
+        float* d = a + lane * PITCH;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- channel contraction on the matrix cores: 2 input channels / MFMA
+    const float* wk = w + (int64_t)k * CIN * COUT;
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s) {
+      const float av = a[i * PITCH + 2 * s + h];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = wk[(2 * s + h) * COUT + t * 32 + i];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int64_t g = row0 + row;
+      if (g < n_out) {
+        float v = acc[t][r];
+        if (relu) v = fmaxf(v, 0.0f);
+        out[g * COUT + t * 32 + i] = v;
+      }
+    }
+  }
+}
+
+// scalar-fmaf reference path on the GPU (any cin/cout), same bits as the MFMA path
+__global__ __launch_bounds__(256) void k_gconv_scalar(
+    const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+    int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int cin, int cout,
+    int relu, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t / cout;
+  const int co = (int)(t - row * cout);
+  if (row >= n_out) return;
+  float acc = bias[co];
+  for (int k = 0; k < k_vol; ++k) {
+    const int32_t nb = nbr[(int64_t)k * pitch + row];
+    if (nb < 0) continue;
+    const float* x = in + (int64_t)nb * cin;
+    const float* wk = w + ((int64_t)k * cin) * cout + co;
+    for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], wk[(int64_t)ci * cout], acc);
+  }
+  if (relu) acc = fmaxf(acc, 0.0f);
+  out[t] = acc;
+}
+
+// generative transposed convolution, kernel 2 stride 2: out[8p+o] = W[o]^T in[p] + b
+template <int NT>
+__global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
+    const float* __restrict__ in, int64_t n_in, const float* __restrict__ w,
+    const float* __restrict__ bias, int relu, float* __restrict__ out) {
+  constexpr int CIN = 32;
+  constexpr int COUT = NT * 32;
+  constexpr int PITCH = CIN + 1;
+  __shared__ float a_lds[GC_WAVES][32 * PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
+  if (row0 >= n_in) return;
+  const int i = lane & 31, h = lane >> 5;
+  float* a = a_lds[wave];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < n_in) v = *reinterpret_cast<const float4*>(in + (row0 + r) * CIN + chunk * 4);
+    float* d = a + r * PITCH + chunk * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float av[CIN / 2];
+#pragma unroll
+  for (int s = 0; s < CIN / 2; ++s) av[s] = a[i * PITCH + 2 * s + h];
+
+  for (int o = 0; o < 8; ++o) {
+    const float* wo = w + (int64_t)o * CIN * COUT;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float b = bias[t * 32 + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = b;
+    }
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = wo[(2 * s + h) * COUT + t * 32 + i];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t p = row0 + row;
+        if (p < n_in) {
+          float v = acc[t][r];
+          if (relu) v = fmaxf(v, 0.0f);
+          out[(p * 8 + o) * COUT + t * 32 + i] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_convT_scalar(
+    const float* __restrict__ in, int64_t n_in, const float* __restrict__ w,
+    const float* __restrict__ bias, int cin, int cout, int relu, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t orow = t / cout;  // 8p+o
+  const int co = (int)(t - orow * cout);
+  if (orow >= n_in * 8) return;
+  const int64_t p = orow >> 3;
+  const int o = (int)(orow & 7);
+  float acc = bias[co];
+  const float* x = in + p * cin;
+  const float* wo = w + ((int64_t)o * cin) * cout + co;
+  for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], wo[(int64_t)ci * cout], acc);
+  if (relu) acc = fmaxf(acc, 0.0f);
+  out[t] = acc;
+}
+
+// 1x1: one thread per (row, co)
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ in, int64_t n,
+                                                const float* __restrict__ w,
+                                                const float* __restrict__ bias, int cin, int cout,
+                                                int relu, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t / cout;
+  const int co = (int)(t - row * cout);
+  if (row >= n) return;
+  float acc = bias[co];
+  const float* x = in + row * cin;
+  for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], w[(int64_t)ci * cout + co], acc);
+  if (relu) acc = fmaxf(acc, 0.0f);
+  out[t] = acc;
+}
+
+// PCC_FORCE_SCALAR=1 in the environment routes every layer through the scalar
+// kernels (used by the parity tests to check MFMA == scalar on the device).
+static bool force_scalar() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PCC_FORCE_SCALAR");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
+                               int k_vol, int64_t nbr_pitch, int64_t n_out, const float* d_w,
+                               const float* d_bias, int cin, int cout, int relu, float* d_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv: null ctx");
+  PCC_REQUIRE(k_vol == 27 || k_vol == 8 || k_vol == 1, PCC_E_ARG, "pcc_sparse_conv: k_vol=%d", k_vol);
+  PCC_REQUIRE(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, PCC_E_ARG,
+              "pcc_sparse_conv: cin=%d cout=%d unsupported", cin, cout);
+  if (n_out <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_nbr && d_w && d_bias && d_out && nbr_pitch >= n_out && n_in > 0, PCC_E_ARG,
+              "pcc_sparse_conv: bad buffers (pitch %lld, n_out %lld, n_in %lld)", (long long)nbr_pitch,
+              (long long)n_out, (long long)n_in);
+  hipStream_t st = ctx->stream;
+  const unsigned gm = nblk(n_out, 32 * GC_WAVES);
+  const bool aligned = ((uintptr_t)d_in % 16 == 0);
+  if (!force_scalar() && aligned && cin == 32 && cout == 32) {
+    hipLaunchKernelGGL((k_gconv_mfma<32, 1>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
+                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+  } else if (!force_scalar() && aligned && cin == 32 && cout == 64) {
+    hipLaunchKernelGGL((k_gconv_mfma<32, 2>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
+                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+  } else if (!force_scalar() && aligned && cin == 4 && cout == 32) {
+    hipLaunchKernelGGL((k_gconv_mfma<4, 1>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
+                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+  } else {
+    hipLaunchKernelGGL(k_gconv_scalar, dim3(nblk(n_out * cout, 256)), dim3(256), 0, st, d_in, d_nbr,
+                       k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out);
+  }
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, const float* d_w,
+                             const float* d_bias, int cin, int cout, int relu, float* d_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_convT_gen: null ctx");
+  PCC_REQUIRE(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, PCC_E_ARG,
+              "pcc_convT_gen: cin=%d cout=%d unsupported", cin, cout);
+  if (n_in <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_w && d_bias && d_out, PCC_E_ARG, "pcc_convT_gen: null buffers");
+  hipStream_t st = ctx->stream;
+  const bool aligned = ((uintptr_t)d_in % 16 == 0);
+  if (!force_scalar() && aligned && cin == 32 && cout == 32) {
+    hipLaunchKernelGGL((k_convT_mfma<1>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
+                       d_in, n_in, d_w, d_bias, relu, d_out);
+  } else if (!force_scalar() && aligned && cin == 32 && cout == 64) {
+    hipLaunchKernelGGL((k_convT_mfma<2>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
+                       d_in, n_in, d_w, d_bias, relu, d_out);
+  } else {
+    hipLaunchKernelGGL(k_convT_scalar, dim3(nblk(n_in * 8 * cout, 256)), dim3(256), 0, st, d_in, n_in,
+                       d_w, d_bias, cin, cout, relu, d_out);
+  }
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const float* d_w,
+                          const float* d_bias, int cin, int cout, int relu, float* d_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_linear: null ctx");
+  PCC_REQUIRE(cin >= 1 && cin <= 256 && cout >= 1 && cout <= 256, PCC_E_ARG,
+              "pcc_linear: cin=%d cout=%d unsupported", cin, cout);
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_w && d_bias && d_out, PCC_E_ARG, "pcc_linear: null buffers");
+  hipLaunchKernelGGL(k_linear, dim3(nblk(n * cout, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
+                     d_bias, cin, cout, relu, d_out);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}

@@ -1,0 +1,226 @@
+// octree_host.cpp — entropy coding of octree occupancy bytes (host side).
+//
+// Host half of the replacement for utils.gpcc_encode / gpcc_decode
+// (shared/utils.py:169-240), which in the reference shell out to MPEG's tmc3
+// once per frame through ASCII PLY temp files.  tmc3 is not in the reference
+// tree and its bitstream cannot be reproduced here, so the blob format below is
+// this build's own (DESIGN.md "points slot"); the container only sees an opaque
+// length-prefixed byte string (codec_pipeline.py:503,510), so the container
+// layout is unchanged.
+//
+// Blob: 'O' ver depth 0 | u32 n_points | i32 origin[3] | u32 payload_len |
+// payload.  Payload = one rANS64 stream (12-bit probabilities, 32-bit words)
+// of the occupancy bytes in breadth-first order (root first, Morton order
+// inside a level), each byte as 8 binary decisions (octant 0..7) under an
+// adaptive context = (level class, bit position, ones so far); the 8th bit is
+// implied when the first seven are zero.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../include/pcc.h"
+
+void pcc_set_error(const char* fmt, ...);
+
+namespace {
+
+constexpr uint32_t kProbBits = 12;
+constexpr uint32_t kProbOne = 1u << kProbBits;
+constexpr uint64_t kRansL = 1ull << 31;
+constexpr int kCtxPerClass = 36;
+constexpr int kClasses = 3;
+constexpr int kHeader = 24;
+
+inline int ctx_index(int depth, int level, int j, int ones) {
+  int cls = depth - 1 - level;
+  if (cls > kClasses - 1) cls = kClasses - 1;
+  return cls * kCtxPerClass + j * (j + 1) / 2 + ones;
+}
+inline void adapt(uint16_t& p1, int bit) {
+  if (bit) p1 = (uint16_t)(p1 + ((kProbOne - p1) >> 4));
+  else p1 = (uint16_t)(p1 - (p1 >> 4));
+}
+inline void put_u32(uint8_t* p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
+inline uint32_t get_u32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// same bit interleave as csrc/common.h (x top bit of each triple), without the bias
+inline uint32_t compact3(uint64_t x) {
+  x &= 0x249249249249ull;
+  x = (x | (x >> 2)) & 0x0C30C30C30C3ull;
+  x = (x | (x >> 4)) & 0x00F00F00F00Full;
+  x = (x | (x >> 8)) & 0x0000FF0000FFull;
+  x = (x | (x >> 16)) & 0xFFFFull;
+  return (uint32_t)x;
+}
+
+}  // namespace
+
+extern "C" int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, int depth,
+                               int64_t n_points, const int32_t* h_origin, uint8_t* h_out, int64_t cap,
+                               int64_t* h_len) {
+  if (!h_out || !h_len || depth < 0 || depth > 16 || n_points < 0 || cap < kHeader ||
+      (n_points > 0 && (!h_occ || !h_level_n || !h_origin || depth < 1))) {
+    pcc_set_error("pcc_octree_pack: bad argument");
+    return PCC_E_ARG;
+  }
+  memset(h_out, 0, kHeader);
+  h_out[0] = 'O';
+  h_out[1] = 1;
+  h_out[2] = (uint8_t)(n_points > 0 ? depth : 0);
+  put_u32(h_out + 4, (uint32_t)n_points);
+  if (n_points == 0) {
+    *h_len = kHeader;
+    return PCC_OK;
+  }
+  for (int a = 0; a < 3; ++a) put_u32(h_out + 8 + 4 * a, (uint32_t)h_origin[a]);
+
+  // forward modelling pass
+  int64_t total_nodes = 0;
+  for (int L = 0; L < depth; ++L) total_nodes += h_level_n[L];
+  std::vector<uint16_t> probs;
+  std::vector<uint8_t> bits;
+  probs.reserve((size_t)total_nodes * 8);
+  bits.reserve((size_t)total_nodes * 8);
+  uint16_t model[kClasses * kCtxPerClass];
+  for (auto& m : model) m = kProbOne / 2;
+  int64_t pos = 0;
+  for (int L = 0; L < depth; ++L) {
+    for (int64_t i = 0; i < h_level_n[L]; ++i, ++pos) {
+      const uint32_t byte = h_occ[pos];
+      if (byte == 0) {
+        pcc_set_error("pcc_octree_pack: empty occupancy byte at level %d node %lld", L, (long long)i);
+        return PCC_E_ARG;
+      }
+      int ones = 0;
+      for (int j = 0; j < 8; ++j) {
+        const int bit = (byte >> j) & 1;
+        if (j == 7 && ones == 0) break;  // implied 1
+        uint16_t& m = model[ctx_index(depth, L, j, ones)];
+        probs.push_back(m);
+        bits.push_back((uint8_t)bit);
+        adapt(m, bit);
+        ones += bit;
+      }
+    }
+  }
+  // reverse rANS pass
+  std::vector<uint32_t> words(bits.size() / 2 + 8);
+  uint32_t* end = words.data() + words.size();
+  uint32_t* ptr = end;
+  uint64_t x = kRansL;
+  for (int64_t k = (int64_t)bits.size() - 1; k >= 0; --k) {
+    const uint32_t p1 = probs[(size_t)k];
+    const uint32_t start = bits[(size_t)k] ? (kProbOne - p1) : 0u;
+    const uint32_t freq = bits[(size_t)k] ? p1 : (kProbOne - p1);
+    const uint64_t x_max = ((kRansL >> kProbBits) << 32) * freq;
+    if (x >= x_max) {
+      if (ptr == words.data()) { pcc_set_error("pcc_octree_pack: internal overflow"); return PCC_E_NOMEM; }
+      *--ptr = (uint32_t)x;
+      x >>= 32;
+    }
+    x = ((x / freq) << kProbBits) + (x % freq) + start;
+  }
+  if (ptr - words.data() < 2) { pcc_set_error("pcc_octree_pack: internal overflow"); return PCC_E_NOMEM; }
+  *--ptr = (uint32_t)(x >> 32);
+  *--ptr = (uint32_t)x;
+  const int64_t payload = (int64_t)(end - ptr) * 4;
+  if (kHeader + payload > cap) {
+    pcc_set_error("pcc_octree_pack: blob needs %lld bytes, capacity %lld", (long long)(kHeader + payload),
+                  (long long)cap);
+    return PCC_E_NOMEM;
+  }
+  put_u32(h_out + 20, (uint32_t)payload);
+  memcpy(h_out + kHeader, ptr, (size_t)payload);
+  *h_len = kHeader + payload;
+  return PCC_OK;
+}
+
+extern "C" int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points, int* h_depth,
+                               int32_t* h_origin) {
+  if (!h_in || len < kHeader || h_in[0] != 'O' || h_in[1] != 1 || h_in[2] > 16) {
+    pcc_set_error("pcc_octree_peek: not an octree blob (len=%lld)", (long long)len);
+    return PCC_E_STREAM;
+  }
+  const int64_t n = (int64_t)get_u32(h_in + 4);
+  const int64_t payload = (int64_t)get_u32(h_in + 20);
+  if (kHeader + payload > len || (n > 0 && (h_in[2] < 1 || payload < 8))) {
+    pcc_set_error("pcc_octree_peek: truncated blob");
+    return PCC_E_STREAM;
+  }
+  if (h_n_points) *h_n_points = n;
+  if (h_depth) *h_depth = h_in[2];
+  if (h_origin)
+    for (int a = 0; a < 3; ++a) h_origin[a] = (int32_t)get_u32(h_in + 8 + 4 * a);
+  return PCC_OK;
+}
+
+extern "C" int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points) {
+  int64_t n = 0;
+  int depth = 0;
+  int32_t origin[3] = {0, 0, 0};
+  const int r = pcc_octree_peek(h_in, len, &n, &depth, origin);
+  if (r != PCC_OK) return r;
+  if (n == 0) return PCC_OK;
+  if (!h_points || cap_points < n) {
+    pcc_set_error("pcc_octree_unpack: output capacity %lld < %lld points", (long long)cap_points,
+                  (long long)n);
+    return PCC_E_ARG;
+  }
+  const uint8_t* p = h_in + kHeader;
+  const uint8_t* end = p + get_u32(h_in + 20);
+  auto word = [&](bool& bad) -> uint32_t {
+    if (end - p < 4) { bad = true; return 0; }
+    const uint32_t w = get_u32(p);
+    p += 4;
+    return w;
+  };
+  bool bad = false;
+  uint64_t x = word(bad);
+  x |= (uint64_t)word(bad) << 32;
+  uint16_t model[kClasses * kCtxPerClass];
+  for (auto& m : model) m = kProbOne / 2;
+  std::vector<uint64_t> cur(1, 0ull), nxt;
+  for (int L = 0; L < depth; ++L) {
+    nxt.clear();
+    for (size_t i = 0; i < cur.size(); ++i) {
+      int ones = 0;
+      for (int j = 0; j < 8; ++j) {
+        int bit;
+        if (j == 7 && ones == 0) {
+          bit = 1;
+        } else {
+          uint16_t& m = model[ctx_index(depth, L, j, ones)];
+          const uint32_t p1 = m;
+          const uint32_t cum = (uint32_t)(x & (kProbOne - 1));
+          bit = cum >= (kProbOne - p1) ? 1 : 0;
+          const uint32_t start = bit ? (kProbOne - p1) : 0u;
+          const uint32_t freq = bit ? p1 : (kProbOne - p1);
+          x = (uint64_t)freq * (x >> kProbBits) + cum - start;
+          if (x < kRansL) x = (x << 32) | word(bad);
+          adapt(m, bit);
+        }
+        if (bit) {
+          nxt.push_back((cur[i] << 3) | (uint64_t)j);
+          ones++;
+        }
+      }
+      if (bad || (int64_t)nxt.size() > n) {
+        pcc_set_error("pcc_octree_unpack: corrupt stream at level %d", L);
+        return PCC_E_STREAM;
+      }
+    }
+    cur.swap(nxt);
+  }
+  if ((int64_t)cur.size() != n) {
+    pcc_set_error("pcc_octree_unpack: decoded %zu points, header says %lld", cur.size(), (long long)n);
+    return PCC_E_STREAM;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t k = cur[(size_t)i];
+    h_points[3 * i + 0] = (int32_t)compact3(k >> 2) + origin[0];
+    h_points[3 * i + 1] = (int32_t)compact3(k >> 1) + origin[1];
+    h_points[3 * i + 2] = (int32_t)compact3(k) + origin[2];
+  }
+  return PCC_OK;
+}

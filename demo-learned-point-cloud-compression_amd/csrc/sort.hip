@@ -1,0 +1,387 @@
+// sort.hip — coordinate keys, stable LSD radix sort, row gathers.
+//
+// Serves: ME.SparseTensor construction (rows are kept in Morton-key order so
+// that stride-2 parents are an adjacent-unique pass and generative children
+// are produced already sorted) and utils.sort_tensor / utils.sort_points
+// (shared/utils.py:116-165) through the exact linear int64 key.
+//
+// Radix sort: 8-bit digits, one wave owns a tile of 64*RS_ROUNDS keys; ranks
+// inside a tile come from wave64 match-ballots (no LDS atomics in the scatter,
+// stable by construction).  Passes whose digit is constant over all keys are
+// skipped (a 512x512x256 room only varies in ~27 Morton bits).
+#include "common.h"
+
+#define RS_ROUNDS 16
+#define RS_WAVE_TILE (64 * RS_ROUNDS)
+#define RS_THREADS 256
+#define RS_WAVES (RS_THREADS / 64)
+
+// ---------------------------------------------------------------- key kernels
+__global__ void k_morton_keys(const int4* __restrict__ coords, int64_t n,
+                              uint64_t* __restrict__ keys, int32_t* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];  // (b,x,y,z)
+  bool bad = (c.x < 0) | (c.x > 65534) | (c.y < -32768) | (c.y > 32767) |
+             (c.z < -32768) | (c.z > 32767) | (c.w < -32768) | (c.w > 32767);
+  if (bad) atomicOr(flag, 1);
+  keys[i] = pcc_morton(c.x, c.y, c.z, c.w);
+}
+
+__global__ void k_keys_to_coords(const uint64_t* __restrict__ keys, int64_t n,
+                                 int4* __restrict__ coords) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b, x, y, z;
+  pcc_unmorton(keys[i], &b, &x, &y, &z);
+  coords[i] = make_int4(b, x, y, z);
+}
+
+__global__ void k_linear_keys(const int4* __restrict__ coords, int64_t n,
+                              int64_t* __restrict__ keys) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  // shared/utils.py:131-132: (C * [1e15,1e10,1e5,1]).sum(dim=1) in int64
+  keys[i] = (int64_t)c.x * 1000000000000000ll + (int64_t)c.y * 10000000000ll +
+            (int64_t)c.z * 100000ll + (int64_t)c.w;
+}
+
+// ---------------------------------------------------------------- radix sort
+// OR / AND of all keys -> which digits vary
+__global__ __launch_bounds__(256) void k_key_bits(const uint64_t* __restrict__ keys,
+                                                  int64_t n, unsigned long long* __restrict__ orand) {
+  uint64_t o = 0, a = ~0ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t k = keys[i];
+    o |= k;
+    a &= k;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    o |= __shfl_xor((unsigned long long)o, d, 64);
+    a &= __shfl_xor((unsigned long long)a, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicOr(&orand[0], (unsigned long long)o);
+    atomicAnd(&orand[1], (unsigned long long)a);
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_count(
+    const uint64_t* __restrict__ keys, int64_t n, int shift, uint64_t flip,
+    uint32_t* __restrict__ counts, int64_t nw) {
+  __shared__ uint32_t cnt[RS_WAVES][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wid = (int64_t)blockIdx.x * RS_WAVES + wave;
+  for (int d = lane; d < 256; d += 64) cnt[wave][d] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (wid < nw) {
+    const int64_t t0 = wid * RS_WAVE_TILE;
+#pragma unroll 4
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+      int64_t e = t0 + r * 64 + lane;
+      if (e < n) {
+        uint32_t d = (uint32_t)(((keys[e] ^ flip) >> shift) & 255u);
+        atomicAdd(&cnt[wave][d], 1u);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int d = lane; d < 256; d += 64) counts[(int64_t)d * nw + wid] = cnt[wave][d];
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in /*null => iota*/,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n,
+    int shift, uint64_t flip, const uint32_t* __restrict__ offsets, int64_t nw) {
+  __shared__ uint32_t base_s[RS_WAVES][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wid = (int64_t)blockIdx.x * RS_WAVES + wave;
+  if (wid >= nw) return;
+  volatile uint32_t* base = base_s[wave];
+  for (int d = lane; d < 256; d += 64) base[d] = offsets[(int64_t)d * nw + wid];
+  __builtin_amdgcn_wave_barrier();
+  const int64_t t0 = wid * RS_WAVE_TILE;
+  const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int64_t e = t0 + r * 64 + lane;
+    const bool valid = e < n;
+    uint64_t key = 0;
+    uint32_t val = 0;
+    if (valid) {
+      key = keys_in[e];
+      val = vals_in ? vals_in[e] : (uint32_t)e;
+    }
+    const uint32_t d = (uint32_t)(((key ^ flip) >> shift) & 255u);
+    uint64_t mask = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      mask &= bit ? bal : ~bal;
+    }
+    const uint32_t rank = (uint32_t)__popcll(mask & lanes_below);
+    const uint32_t cnt = (uint32_t)__popcll(mask);
+    uint32_t pos = 0;
+    if (valid) pos = base[d] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) base[d] = pos + cnt;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+  }
+}
+
+__global__ void k_iota(uint32_t* __restrict__ p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+static size_t sort_scratch_bytes(int64_t n) {
+  const int64_t nw = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
+  return pcc_align((size_t)n * 8) + pcc_align((size_t)n * 4) +
+         pcc_align((size_t)256 * nw * 4) + pcc_scan_scratch_bytes(256 * nw) + 1024;
+}
+
+// Sort with scratch already reserved in the arena.
+static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
+                           int is_signed) {
+  hipStream_t st = ctx->stream;
+  if (n <= 0) return PCC_OK;
+  if (n == 1) {
+    hipLaunchKernelGGL(k_iota, dim3(1), dim3(64), 0, st, d_perm, n);
+    PCC_CHECK_LAUNCH();
+    return PCC_OK;
+  }
+  const int64_t nw = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
+  uint64_t* tmp_k = (uint64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
+  uint32_t* tmp_v = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
+  uint32_t* counts = (uint32_t*)pcc_arena_alloc(ctx, (size_t)256 * nw * 4);
+  unsigned long long* orand = (unsigned long long*)pcc_arena_alloc(ctx, 16);
+  if (!tmp_k || !tmp_v || !counts || !orand) return PCC_E_NOMEM;
+  const size_t arena_mark = ctx->arena_off;
+
+  // which digits vary?
+  unsigned long long init[2] = {0ull, ~0ull};
+  unsigned long long* h = (unsigned long long*)ctx->pinned;
+  h[0] = init[0];
+  h[1] = init[1];
+  PCC_HIP(hipMemcpyAsync(orand, h, 16, hipMemcpyHostToDevice, st));
+  unsigned g = nblk(n, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_key_bits, dim3(g), dim3(256), 0, st, d_keys, n, orand);
+  PCC_CHECK_LAUNCH();
+  PCC_HIP(hipMemcpyAsync(h, orand, 16, hipMemcpyDeviceToHost, st));
+  PCC_HIP(hipStreamSynchronize(st));
+  const uint64_t varying = h[0] & ~h[1];
+  const uint64_t flip = is_signed ? (1ull << 63) : 0ull;
+
+  uint64_t* kin = d_keys;
+  uint64_t* kout = tmp_k;
+  uint32_t* vin = nullptr;  // iota on the first executed pass
+  uint32_t* vout = tmp_v;
+  // ping-pong targets for values: d_perm and tmp_v
+  int executed = 0;
+  const unsigned gblk = nblk(nw, RS_WAVES);
+  for (int p = 0; p < 8; ++p) {
+    if (((varying >> (8 * p)) & 0xFFull) == 0) continue;
+    const int shift = 8 * p;
+    ctx->arena_off = arena_mark;  // scan scratch is reusable per pass
+    hipLaunchKernelGGL(k_radix_count, dim3(gblk), dim3(RS_THREADS), 0, st, kin, n, shift,
+                       flip, counts, nw);
+    PCC_CHECK_LAUNCH();
+    PCC_TRY(pcc_scan_exclusive_u32(ctx, counts, counts, 256 * nw, nullptr));
+    vout = (executed % 2 == 0) ? tmp_v : d_perm;
+    hipLaunchKernelGGL(k_radix_scatter, dim3(gblk), dim3(RS_THREADS), 0, st, kin,
+                       (const uint32_t*)vin, kout, vout, n, shift, flip,
+                       (const uint32_t*)counts, nw);
+    PCC_CHECK_LAUNCH();
+    // swap
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    vin = vout;
+    ++executed;
+  }
+  if (executed == 0) {
+    hipLaunchKernelGGL(k_iota, dim3(nblk(n, 256)), dim3(256), 0, st, d_perm, n);
+    PCC_CHECK_LAUNCH();
+    return PCC_OK;
+  }
+  if (kin != d_keys)
+    PCC_HIP(hipMemcpyAsync(d_keys, kin, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  if (vin != d_perm)
+    PCC_HIP(hipMemcpyAsync(d_perm, vin, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+  return PCC_OK;
+}
+
+// ---------------------------------------------------------------- misc kernels
+__global__ void k_gather_rows16(const uint4* __restrict__ src, const uint32_t* __restrict__ perm,
+                                int64_t n, int vec, uint4* __restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = t / vec;
+  int j = (int)(t - row * vec);
+  if (row >= n) return;
+  dst[row * vec + j] = src[(int64_t)perm[row] * vec + j];
+}
+__global__ void k_gather_rows4(const uint32_t* __restrict__ src, const uint32_t* __restrict__ perm,
+                               int64_t n, int vec, uint32_t* __restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = t / vec;
+  int j = (int)(t - row * vec);
+  if (row >= n) return;
+  dst[row * vec + j] = src[(int64_t)perm[row] * vec + j];
+}
+__global__ void k_gather_rows_or_zero(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                      int64_t m, int c, float* __restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = t / c;
+  int j = (int)(t - row * c);
+  if (row >= m) return;
+  int32_t r = rows[row];
+  dst[t] = r >= 0 ? src[(int64_t)r * c + j] : 0.0f;
+}
+
+__global__ void k_check_unique(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 < n && keys[i] == keys[i + 1]) atomicOr(flag, 1);
+}
+
+// offsets[b] = lower_bound(keys, b<<48)
+__global__ void k_batch_offsets(const uint64_t* __restrict__ keys, int64_t n, int n_batch,
+                                int64_t* __restrict__ offs) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > n_batch) return;
+  const uint64_t target = (uint64_t)b << 48;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  offs[b] = lo;
+}
+
+// ---------------------------------------------------------------- C-ABI
+extern "C" int pcc_morton_keys(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
+                               uint64_t* d_keys, int32_t* d_flag) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_keys && d_flag)), PCC_E_ARG, "pcc_morton_keys: null arg");
+  if (n <= 0) return PCC_OK;
+  hipLaunchKernelGGL(k_morton_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                     (const int4*)d_coords, n, d_keys, d_flag);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_keys_to_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                                  int32_t* d_coords) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_keys)), PCC_E_ARG, "pcc_keys_to_coords: null arg");
+  if (n <= 0) return PCC_OK;
+  hipLaunchKernelGGL(k_keys_to_coords, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_keys, n,
+                     (int4*)d_coords);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_linear_keys(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
+                               int64_t* d_keys) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_keys)), PCC_E_ARG, "pcc_linear_keys: null arg");
+  if (n <= 0) return PCC_OK;
+  hipLaunchKernelGGL(k_linear_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                     (const int4*)d_coords, n, d_keys);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_sort_pairs(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
+                              int is_signed) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_keys && d_perm)), PCC_E_ARG, "pcc_sort_pairs: null arg");
+  PCC_REQUIRE(n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_sort_pairs: n too large");
+  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n)));
+  return sort_pairs_impl(ctx, d_keys, d_perm, n, is_signed);
+}
+
+extern "C" int pcc_sort_coords(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
+                               uint32_t* d_perm) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_perm)), PCC_E_ARG, "pcc_sort_coords: null arg");
+  PCC_REQUIRE(n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_sort_coords: n too large");
+  if (n <= 0) return PCC_OK;
+  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n) + pcc_align((size_t)n * 8)));
+  int64_t* lk = (int64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
+  if (!lk) return PCC_E_NOMEM;
+  hipLaunchKernelGGL(k_linear_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                     (const int4*)d_coords, n, lk);
+  PCC_CHECK_LAUNCH();
+  return sort_pairs_impl(ctx, (uint64_t*)lk, d_perm, n, 1);
+}
+
+extern "C" int pcc_gather_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* d_perm,
+                               int64_t n, int row_bytes, void* d_dst) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_src && d_perm && d_dst)), PCC_E_ARG, "pcc_gather_rows: null arg");
+  PCC_REQUIRE(row_bytes > 0 && row_bytes % 4 == 0, PCC_E_ARG, "pcc_gather_rows: row_bytes %d", row_bytes);
+  if (n <= 0) return PCC_OK;
+  if (row_bytes % 16 == 0 && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0)) {
+    int vec = row_bytes / 16;
+    hipLaunchKernelGGL(k_gather_rows16, dim3(nblk(n * vec, 256)), dim3(256), 0, ctx->stream,
+                       (const uint4*)d_src, d_perm, n, vec, (uint4*)d_dst);
+  } else {
+    int vec = row_bytes / 4;
+    hipLaunchKernelGGL(k_gather_rows4, dim3(nblk(n * vec, 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_src, d_perm, n, vec, (uint32_t*)d_dst);
+  }
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gather_rows_or_zero(pcc_ctx* ctx, const float* d_src, const int32_t* d_rows,
+                                       int64_t m, int c, float* d_dst) {
+  PCC_REQUIRE(ctx && (m == 0 || (d_src && d_rows && d_dst)), PCC_E_ARG, "pcc_gather_rows_or_zero: null arg");
+  PCC_REQUIRE(c > 0, PCC_E_ARG, "pcc_gather_rows_or_zero: c=%d", c);
+  if (m <= 0) return PCC_OK;
+  hipLaunchKernelGGL(k_gather_rows_or_zero, dim3(nblk(m * c, 256)), dim3(256), 0, ctx->stream,
+                     d_src, d_rows, m, c, d_dst);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_check_unique(pcc_ctx* ctx, const uint64_t* d_sorted_keys, int64_t n, int* h_dup) {
+  PCC_REQUIRE(ctx && h_dup && (n == 0 || d_sorted_keys), PCC_E_ARG, "pcc_check_unique: null arg");
+  *h_dup = 0;
+  if (n <= 1) return PCC_OK;
+  PCC_TRY(pcc_arena_reserve(ctx, 256));
+  int32_t* flag = (int32_t*)pcc_arena_alloc(ctx, 4);
+  if (!flag) return PCC_E_NOMEM;
+  PCC_HIP(hipMemsetAsync(flag, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_check_unique, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_sorted_keys, n, flag);
+  PCC_CHECK_LAUNCH();
+  int32_t* h = (int32_t*)ctx->pinned;
+  PCC_HIP(hipMemcpyAsync(h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  *h_dup = h[0];
+  return PCC_OK;
+}
+
+extern "C" int pcc_batch_offsets(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int n_batch,
+                                 int64_t* h_offsets) {
+  PCC_REQUIRE(ctx && h_offsets && (n == 0 || d_keys), PCC_E_ARG, "pcc_batch_offsets: null arg");
+  PCC_REQUIRE(n_batch >= 0 && (size_t)(n_batch + 1) * 8 <= ctx->pinned_cap, PCC_E_ARG,
+              "pcc_batch_offsets: n_batch=%d unsupported", n_batch);
+  if (n <= 0) {
+    for (int b = 0; b <= n_batch; ++b) h_offsets[b] = 0;
+    return PCC_OK;
+  }
+  PCC_TRY(pcc_arena_reserve(ctx, (size_t)(n_batch + 1) * 8 + 256));
+  int64_t* offs = (int64_t*)pcc_arena_alloc(ctx, (size_t)(n_batch + 1) * 8);
+  if (!offs) return PCC_E_NOMEM;
+  hipLaunchKernelGGL(k_batch_offsets, dim3(nblk(n_batch + 1, 64)), dim3(64), 0, ctx->stream, d_keys, n,
+                     n_batch, offs);
+  PCC_CHECK_LAUNCH();
+  PCC_HIP(hipMemcpyAsync(ctx->pinned, offs, (size_t)(n_batch + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b <= n_batch; ++b) h_offsets[b] = ((int64_t*)ctx->pinned)[b];
+  return PCC_OK;
+}

@@ -1,0 +1,105 @@
+"""Entropy models with the CompressAI method names the reference calls
+(SURVEY.md §8b): `entropy_bottleneck.compress/decompress`,
+`gaussian_conditional.build_indexes/compress/decompress/lower_bound_scale`.
+
+Symbol and index formation runs on the GPU (csrc/entropy.hip); the serial
+rANS stream itself is coded on the host by the C++ coder in libpcc_hip.so
+(csrc/rans_host.cpp), bit-compatible with CompressAI's format.  Tensors keep
+CompressAI's [B, C, N] layout at this surface.
+"""
+import numpy as np
+import torch
+
+from . import runtime as _rt
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+class _Coder:
+    def __init__(self, cdf, length, offset):
+        self.cdf = np.ascontiguousarray(cdf, dtype=np.int32)
+        self.length = np.ascontiguousarray(length, dtype=np.int32)
+        self.offset = np.ascontiguousarray(offset, dtype=np.int32)
+
+    def encode(self, sym, idx):
+        """sym, idx: int32 numpy [S, n] -> list of S byte strings"""
+        return _rt.rans_encode_multi(np.ascontiguousarray(sym), np.ascontiguousarray(idx), self.cdf, self.length,
+                                     self.offset)
+
+    def decode(self, data, idx):
+        return _rt.rans_decode(data, np.ascontiguousarray(idx, dtype=np.int32), self.cdf, self.length, self.offset)
+
+
+class EntropyBottleneck:
+    """factorized prior over z: per-channel CDF, symbols = round(z - median)."""
+
+    def __init__(self, tensors, params):
+        self.coder = _Coder(tensors["entropy_bottleneck.quantized_cdf"], tensors["entropy_bottleneck.cdf_length"],
+                            tensors["entropy_bottleneck.offset"])
+        self.medians_host = tensors["entropy_bottleneck.medians"].astype(np.float32)
+        self.medians = _dev(self.medians_host, params.dev["g_a.conv0.weight"].device)
+        self.channels = int(self.medians_host.shape[0])
+
+    def _indexes(self, n):
+        return np.repeat(np.arange(self.channels, dtype=np.int32), n)
+
+    # fused form used by the pipeline: z rows [N,C] in coding order
+    def compress_rows(self, rt, z_rows):
+        sym, zhat = rt.factorized_quant(z_rows, self.medians)
+        n = z_rows.shape[0]
+        sym_h = sym.cpu().numpy().reshape(1, -1)
+        strings = self.coder.encode(sym_h, self._indexes(n).reshape(1, -1))
+        return strings, zhat
+
+    def decompress_rows(self, rt, strings, n):
+        sym = self.coder.decode(strings[0], self._indexes(n))
+        sym_d = rt.to_device(sym.reshape(self.channels, n), torch.int32)
+        return rt.factorized_dequant(sym_d, self.medians)
+
+    # CompressAI-shaped surface ([1,C,N] tensors)
+    def compress(self, x):
+        rt = _rt.current()
+        assert x.dim() == 3 and x.shape[0] == 1
+        rows = x[0].t().contiguous()
+        strings, _ = self.compress_rows(rt, rows)
+        return strings
+
+    def decompress(self, strings, size):
+        rt = _rt.current()
+        n = int(size[0] if not isinstance(size[0], (list, tuple)) else size[0][0])
+        zhat = self.decompress_rows(rt, strings, n)
+        return zhat.t().contiguous().unsqueeze(0)
+
+
+class GaussianConditional:
+    """conditional Gaussian prior over y: CDF chosen per element by a scale index."""
+
+    def __init__(self, tensors, params):
+        self.coder = _Coder(tensors["gaussian_conditional.quantized_cdf"],
+                            tensors["gaussian_conditional.cdf_length"], tensors["gaussian_conditional.offset"])
+        self.scale_table_host = tensors["gaussian_conditional.scale_table"].astype(np.float32)
+        self.scale_table = _dev(self.scale_table_host, params.dev["g_a.conv0.weight"].device)
+        self.scale_bound = np.float32(self.scale_table_host[0])
+
+    def lower_bound_scale(self, scales):
+        return torch.clamp(scales, min=float(self.scale_bound))
+
+    # fused forms used by the pipeline ------------------------------------
+    def compress_rows(self, rt, y_rows, params_rows, scale_q):
+        """y_rows [N,C], params_rows [N,2C], scale_q device [Q,C] -> Q byte strings"""
+        sym, idx = rt.gaussian_quant(y_rows, params_rows, scale_q, self.scale_table)
+        q = scale_q.shape[0]
+        sym_h = sym.cpu().numpy().reshape(q, -1)
+        idx_h = idx.cpu().numpy().reshape(q, -1)
+        return self.coder.encode(sym_h, idx_h)
+
+    def decompress_rows(self, rt, string, params_rows, scale_1, off_a, off_b):
+        """one quality: returns y_hat rows [N,C] (offset de-quantisation applied)"""
+        n, c = params_rows.shape[0], params_rows.shape[1] // 2
+        idx = rt.gaussian_indexes(params_rows, scale_1, self.scale_table)
+        sym = self.coder.decode(string, idx.cpu().numpy().reshape(-1))
+        sym_d = rt.to_device(sym.reshape(c, n), torch.int32)
+        return rt.gaussian_dequant(sym_d, params_rows, scale_1, float(self.scale_bound), float(off_a),
+                                   float(off_b))

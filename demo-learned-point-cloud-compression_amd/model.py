@@ -1,0 +1,218 @@
+"""ColorModel — the model surface the reference codec calls
+(`from unified.model import model; model.ColorModel(config["model"])`,
+sender/encoder/codec_pipeline.py:14,65).  The upstream model package and its
+weights are not in the reference tree, so the architecture is
+this build's own, frozen in DESIGN.md §MODEL; what is mirrored is the operator
+surface the two pipelines use:
+
+    model.g_a(x) -> (y, k)                 analysis, stride 1 -> 8
+    model.g_s(y_hat, k=ks) -> x_hat        synthesis with per-frame top-k pruning
+    model.g_s.down_conv(st) -> st          stride-2 coordinate map only
+    model.entropy_model.h_a / h_s / scale_nn / eps / get_offsets
+    model.entropy_model.entropy_bottleneck / gaussian_conditional
+    model.update() / .eval() / .to()
+
+Every layer is a call into libpcc_hip.so through the active Runtime.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import runtime as _rt
+from .sparse import SparseTensor, CoordSet
+from .entropy import EntropyBottleneck, GaussianConditional
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def load_checkpoint(name="demo_small"):
+    path = os.path.join(ASSETS, name + ".npz")
+    with np.load(path) as f:
+        return {k: f[k] for k in f.files}
+
+
+class _Params:
+    """device-resident weights, one copy per device"""
+
+    def __init__(self, tensors, device):
+        self.host = tensors
+        self.dev = {}
+        for k, v in tensors.items():
+            if (k.endswith(".weight") or k.endswith(".bias")) and not k.startswith("scale_nn"):
+                self.dev[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device)
+
+    def wb(self, name):
+        return self.dev[name + ".weight"], self.dev[name + ".bias"]
+
+
+def conv3(p, name, x, relu):
+    rt = x.rt
+    w, b = p.wb(name)
+    return SparseTensor(rt.sparse_conv(x.F, x.cs.nbr27(), w, b, relu), coordset=x.cs)
+
+
+def down2(p, name, x, relu):
+    rt = x.rt
+    w, b = p.wb(name)
+    pcs, nbr8 = x.cs.down()
+    return SparseTensor(rt.sparse_conv(x.F, nbr8, w, b, relu), coordset=pcs)
+
+
+def up2(p, name, x, relu):
+    rt = x.rt
+    w, b = p.wb(name)
+    return SparseTensor(rt.convT_gen(x.F, w, b, relu), coordset=x.cs.up())
+
+
+def linear(p, name, x, relu=False):
+    w, b = p.wb(name)
+    return x.rt.linear(x.F, w, b, relu)
+
+
+class AnalysisTransform:
+    """g_a: 3 x (conv3 + ReLU, stride-2 conv + ReLU), final conv3 -> C_y.
+    Returns (y, k) with k[scale][frame] = voxel count of that frame at strides
+    4, 2, 1 (coarse -> fine), consumed by g_s as the top-k sizes."""
+
+    def __init__(self, params):
+        self.p = params
+
+    def __call__(self, x):
+        p = self.p
+        counts = []
+        h = x
+        for j in range(3):
+            offs = h.cs.offsets
+            counts.append([offs[i + 1] - offs[i] for i in range(h.cs.n_batch)])
+            h = conv3(p, f"g_a.conv{j}", h, True)
+            h = down2(p, f"g_a.down{j}", h, True)
+            h.cs.set_batches(x.cs.n_batch)
+        y = conv3(p, "g_a.conv3", h, False)
+        k = [counts[2], counts[1], counts[0]]
+        return y, k
+
+
+class SynthesisTransform:
+    """g_s: 3 x (generative up + ReLU, conv3 + ReLU, 1x1 occupancy logit,
+    per-frame top-k prune), then a 1x1 colour head."""
+
+    def __init__(self, params):
+        self.p = params
+
+    def down_conv(self, st):
+        # only the output coordinate set is consumed (codec_parallel.py:302-305)
+        pcs, _ = st.cs.down()
+        return SparseTensor(None, coordset=pcs)
+
+    def __call__(self, y_hat, k):
+        p = self.p
+        h = y_hat
+        n_batch = h.cs.n_batch
+        _ = h.cs.offsets
+        for j in range(3):
+            h = up2(p, f"g_s.up{j}", h, True)
+            h = conv3(p, f"g_s.conv{j}", h, True)
+            logits = linear(p, f"g_s.occ{j}", h)
+            offs = h.cs.offsets
+            kj = [min(int(k[j][f]), offs[f + 1] - offs[f]) for f in range(n_batch)]
+            keep = h.rt.topk_prune(logits.view(-1), offs, kj)
+            new_offs = [0]
+            for v in kj:
+                new_offs.append(new_offs[-1] + v)
+            cs = h.cs.subset(keep, n_batch, new_offs)
+            h = SparseTensor(h.rt.gather_rows(h.F, keep), coordset=cs)
+        rgb = linear(p, "g_s.color", h)
+        return SparseTensor(rgb, coordset=h.cs)
+
+
+class HyperAnalysis:
+    def __init__(self, params):
+        self.p = params
+
+    def __call__(self, y):
+        h = conv3(self.p, "h_a.conv0", y, True)
+        h = down2(self.p, "h_a.down0", h, True)
+        return down2(self.p, "h_a.down1", h, False)
+
+
+class HyperSynthesis:
+    def __init__(self, params):
+        self.p = params
+
+    def __call__(self, z_hat):
+        h = up2(self.p, "h_s.up0", z_hat, True)
+        h = up2(self.p, "h_s.up1", h, True)
+        return conv3(self.p, "h_s.conv0", h, False)
+
+
+class ScaleNN:
+    """scale_nn(q[1,2]) -> [1,C_y].  Evaluated on the host in float32 with a
+    fixed operation order and no transcendental function, so encoder, decoder
+    and oracle get identical bits: s = 0.5 + |relu(q W0 + b0) W1 + b1|."""
+
+    def __init__(self, t):
+        self.w0, self.b0 = t["scale_nn.l0.weight"], t["scale_nn.l0.bias"]
+        self.w1, self.b1 = t["scale_nn.l1.weight"], t["scale_nn.l1.bias"]
+
+    def __call__(self, q):
+        q = np.asarray(q.detach().cpu().numpy() if isinstance(q, torch.Tensor) else q, dtype=np.float32)
+        q = q.reshape(-1, 2)
+        out = np.empty((q.shape[0], self.w1.shape[1]), dtype=np.float32)
+        for r in range(q.shape[0]):
+            h = self.b0.copy()
+            for i in range(2):
+                h = (h + q[r, i] * self.w0[i]).astype(np.float32)
+            h = np.maximum(h, np.float32(0))
+            o = self.b1.copy()
+            for i in range(h.shape[0]):
+                o = (o + h[i] * self.w1[i]).astype(np.float32)
+            out[r] = np.float32(0.5) + np.abs(o)
+        return out
+
+
+class EntropyModel:
+    def __init__(self, tensors, params):
+        self.h_a = HyperAnalysis(params)
+        self.h_s = HyperSynthesis(params)
+        self.scale_nn = ScaleNN(tensors)
+        self.eps = np.float32(tensors["entropy_model.eps"])
+        self.offsets_ab = tensors["entropy_model.offsets_ab"].astype(np.float32)
+        self.entropy_bottleneck = EntropyBottleneck(tensors, params)
+        self.gaussian_conditional = GaussianConditional(tensors, params)
+
+    def get_offsets(self, stdev, scale=None):
+        """de-quantisation offset as a function of the (scaled) stdev; `scale`
+        is accepted for signature parity (codec_parallel.py:405)."""
+        a, b = self.offsets_ab
+        return a / (b + stdev)
+
+
+class ColorModel:
+    def __init__(self, config=None):
+        self.config = config or {"name": "demo_small"}
+        self.tensors = load_checkpoint(self.config.get("name", "demo_small"))
+        self.device = None
+        self.params = None
+        self.g_a = self.g_s = self.entropy_model = None
+
+    def load_state_dict(self, state):
+        if state:
+            self.tensors.update({k: np.asarray(v) for k, v in state.items()})
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.params = _Params(self.tensors, self.device)
+        self.g_a = AnalysisTransform(self.params)
+        self.g_s = SynthesisTransform(self.params)
+        self.entropy_model = EntropyModel(self.tensors, self.params)
+        return self
+
+    def update(self):
+        # CompressAI's update() builds the integer CDF tables; here they ship
+        # pre-quantised in the checkpoint (tools/make_checkpoint.py).
+        return True
+
+    def eval(self):
+        return self

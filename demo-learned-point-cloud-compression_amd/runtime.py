@@ -1,0 +1,337 @@
+"""Runtime: one pcc_ctx (device + HIP stream + scratch arena) with tensor-level
+wrappers around the C-ABI.
+
+torch is used here for what the task allows it for — device memory (caching
+allocator), streams and host<->device copies.  Every computation on device
+tensors goes through libpcc_hip.so; nothing here computes with torch ops.
+One Runtime per in-flight compress()/decompress() call (the reference runs up
+to three concurrent calls, sender/encoder/encoder.py:50).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import check, PccError
+
+_tls = threading.local()
+
+
+def current():
+    rt = getattr(_tls, "rt", None)
+    if rt is None:
+        raise RuntimeError("no active pcc Runtime on this thread (use `with runtime:`)")
+    return rt
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Runtime:
+    def __init__(self, device=0, stream=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pcc Runtime needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = _abi.lib()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self.ctx = self.lib.pcc_create(device, C.c_void_p(self.stream.cuda_stream))
+        if not self.ctx:
+            raise PccError(-2, "pcc_create", self.lib.pcc_last_error().decode())
+        self._stream_cm = None
+        self._prev = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.pcc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # `with rt:` makes rt the thread's active runtime and its stream torch's current stream
+    def __enter__(self):
+        self._prev = getattr(_tls, "rt", None)
+        _tls.rt = self
+        self._stream_cm = torch.cuda.stream(self.stream)
+        self._stream_cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._stream_cm.__exit__(*exc)
+        _tls.rt = self._prev
+        return False
+
+    # ------------------------------------------------------------ helpers
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def sync(self):
+        check(self.lib.pcc_sync(self.ctx), "pcc_sync")
+
+    def to_device(self, a, dtype=None):
+        """host numpy / torch -> device tensor on this runtime's stream"""
+        if isinstance(a, torch.Tensor):
+            t = a
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        if t.device != self.device:
+            t = t.to(self.device, non_blocking=True)
+        return t.contiguous()
+
+    def timer_start(self):
+        check(self.lib.pcc_timer_start(self.ctx), "pcc_timer_start")
+
+    def timer_stop_ms(self):
+        check(self.lib.pcc_timer_stop(self.ctx), "pcc_timer_stop")
+        ms = C.c_float(0)
+        check(self.lib.pcc_timer_elapsed_ms(self.ctx, C.byref(ms)), "pcc_timer_elapsed_ms")
+        return ms.value
+
+    # ------------------------------------------------------------ keys / order
+    def morton_keys(self, coords):
+        n = coords.shape[0]
+        keys = self.empty((n,), torch.int64)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(self.lib.pcc_morton_keys(self.ctx, _ptr(coords), n, _ptr(keys), _ptr(flag)), "pcc_morton_keys")
+        if n and int(flag.item()) != 0:
+            raise PccError(_abi.PCC_E_RANGE, "pcc_morton_keys",
+                           "coordinate outside [-32768,32767] or batch index outside [0,65534]")
+        return keys
+
+    def keys_to_coords(self, keys):
+        n = keys.shape[0]
+        coords = self.empty((n, 4), torch.int32)
+        check(self.lib.pcc_keys_to_coords(self.ctx, _ptr(keys), n, _ptr(coords)), "pcc_keys_to_coords")
+        return coords
+
+    def linear_keys(self, coords):
+        n = coords.shape[0]
+        keys = self.empty((n,), torch.int64)
+        check(self.lib.pcc_linear_keys(self.ctx, _ptr(coords), n, _ptr(keys)), "pcc_linear_keys")
+        return keys
+
+    def sort_pairs(self, keys, signed=False):
+        """sorts `keys` in place, returns the permutation (int32 tensor holding uint32 indices)"""
+        n = keys.shape[0]
+        perm = self.empty((n,), torch.int32)
+        check(self.lib.pcc_sort_pairs(self.ctx, _ptr(keys), _ptr(perm), n, 1 if signed else 0), "pcc_sort_pairs")
+        return perm
+
+    def sort_coords(self, coords):
+        n = coords.shape[0]
+        perm = self.empty((n,), torch.int32)
+        check(self.lib.pcc_sort_coords(self.ctx, _ptr(coords), n, _ptr(perm)), "pcc_sort_coords")
+        return perm
+
+    def gather_rows(self, src, perm):
+        n = perm.shape[0]
+        row_elems = 1
+        for d in src.shape[1:]:
+            row_elems *= int(d)
+        row_bytes = src.element_size() * row_elems
+        dst = self.empty((n,) + tuple(src.shape[1:]), src.dtype)
+        check(self.lib.pcc_gather_rows(self.ctx, _ptr(src), _ptr(perm), n, row_bytes, _ptr(dst)), "pcc_gather_rows")
+        return dst
+
+    def check_unique(self, sorted_keys):
+        dup = C.c_int(0)
+        check(self.lib.pcc_check_unique(self.ctx, _ptr(sorted_keys), sorted_keys.shape[0], C.byref(dup)),
+              "pcc_check_unique")
+        return dup.value == 0
+
+    def batch_offsets(self, keys, n_batch):
+        out = (C.c_int64 * (n_batch + 1))()
+        check(self.lib.pcc_batch_offsets(self.ctx, _ptr(keys), keys.shape[0], n_batch, out), "pcc_batch_offsets")
+        return [int(v) for v in out]
+
+    # ------------------------------------------------------------ pyramid / maps
+    def down_coords(self, keys, child_shift):
+        n = keys.shape[0]
+        pkeys = self.empty((n,), torch.int64)
+        nbr8 = self.empty((8 * n,), torch.int32)
+        m = C.c_int64(0)
+        check(self.lib.pcc_down_coords(self.ctx, _ptr(keys), n, child_shift, _ptr(pkeys), _ptr(nbr8), n,
+                                       C.byref(m)), "pcc_down_coords")
+        m = m.value
+        return pkeys[:m], nbr8[:8 * m].view(8, m)
+
+    def up_coords(self, keys, child_shift):
+        n = keys.shape[0]
+        ckeys = self.empty((8 * n,), torch.int64)
+        check(self.lib.pcc_up_coords(self.ctx, _ptr(keys), n, child_shift, _ptr(ckeys)), "pcc_up_coords")
+        return ckeys
+
+    def build_map(self, keys, stride):
+        n = keys.shape[0]
+        nbr = self.empty((27, n), torch.int32)
+        check(self.lib.pcc_build_map(self.ctx, _ptr(keys), n, stride, _ptr(nbr)), "pcc_build_map")
+        return nbr
+
+    def lookup(self, keys, qkeys):
+        m = qkeys.shape[0]
+        rows = self.empty((m,), torch.int32)
+        check(self.lib.pcc_lookup(self.ctx, _ptr(keys), keys.shape[0], _ptr(qkeys), m, _ptr(rows)), "pcc_lookup")
+        return rows
+
+    def gather_rows_or_zero(self, src, rows):
+        m, c = rows.shape[0], src.shape[1]
+        dst = self.empty((m, c), torch.float32)
+        check(self.lib.pcc_gather_rows_or_zero(self.ctx, _ptr(src), _ptr(rows), m, c, _ptr(dst)),
+              "pcc_gather_rows_or_zero")
+        return dst
+
+    # ------------------------------------------------------------ layers
+    def sparse_conv(self, x, nbr, w, b, relu):
+        k_vol, n_out = nbr.shape
+        cin, cout = w.shape[1], w.shape[2]
+        assert x.shape[1] == cin and w.shape[0] == k_vol, (x.shape, w.shape, nbr.shape)
+        out = self.empty((n_out, cout), torch.float32)
+        check(self.lib.pcc_sparse_conv(self.ctx, _ptr(x), x.shape[0], _ptr(nbr), k_vol, nbr.stride(0), n_out,
+                                       _ptr(w), _ptr(b), cin, cout, 1 if relu else 0, _ptr(out)),
+              "pcc_sparse_conv")
+        return out
+
+    def convT_gen(self, x, w, b, relu):
+        n, cin, cout = x.shape[0], w.shape[1], w.shape[2]
+        assert x.shape[1] == cin and w.shape[0] == 8
+        out = self.empty((8 * n, cout), torch.float32)
+        check(self.lib.pcc_convT_gen(self.ctx, _ptr(x), n, _ptr(w), _ptr(b), cin, cout, 1 if relu else 0,
+                                     _ptr(out)), "pcc_convT_gen")
+        return out
+
+    def linear(self, x, w, b, relu):
+        n, cin, cout = x.shape[0], w.shape[0], w.shape[1]
+        assert x.shape[1] == cin
+        out = self.empty((n, cout), torch.float32)
+        check(self.lib.pcc_linear(self.ctx, _ptr(x), n, _ptr(w), _ptr(b), cin, cout, 1 if relu else 0, _ptr(out)),
+              "pcc_linear")
+        return out
+
+    def topk_prune(self, logits, offsets, k):
+        n, nb = logits.shape[0], len(k)
+        keep = self.empty((n,), torch.int32)
+        offs = (C.c_int64 * (nb + 1))(*offsets)
+        ks = (C.c_int64 * nb)(*k)
+        nk = C.c_int64(0)
+        check(self.lib.pcc_topk_prune(self.ctx, _ptr(logits), n, nb, offs, ks, _ptr(keep), C.byref(nk)),
+              "pcc_topk_prune")
+        return keep[:nk.value]
+
+    # ------------------------------------------------------------ entropy (device part)
+    def factorized_quant(self, z, med):
+        n, c = z.shape
+        sym = self.empty((c, n), torch.int32)
+        zhat = self.empty((n, c), torch.float32)
+        check(self.lib.pcc_factorized_quant(self.ctx, _ptr(z), n, c, _ptr(med), _ptr(sym), _ptr(zhat)),
+              "pcc_factorized_quant")
+        return sym, zhat
+
+    def factorized_dequant(self, sym, med):
+        c, n = sym.shape
+        zhat = self.empty((n, c), torch.float32)
+        check(self.lib.pcc_factorized_dequant(self.ctx, _ptr(sym), n, c, _ptr(med), _ptr(zhat)),
+              "pcc_factorized_dequant")
+        return zhat
+
+    def gaussian_quant(self, y, params, scale, table):
+        n, c = y.shape
+        q = scale.shape[0]
+        sym = self.empty((q, c, n), torch.int32)
+        idx = self.empty((q, c, n), torch.int32)
+        check(self.lib.pcc_gaussian_quant(self.ctx, _ptr(y), _ptr(params), n, c, _ptr(scale), q, _ptr(table),
+                                          table.shape[0], _ptr(sym), _ptr(idx)), "pcc_gaussian_quant")
+        return sym, idx
+
+    def gaussian_indexes(self, params, scale, table):
+        n, c = params.shape[0], params.shape[1] // 2
+        idx = self.empty((c, n), torch.int32)
+        check(self.lib.pcc_gaussian_indexes(self.ctx, _ptr(params), n, c, _ptr(scale), _ptr(table),
+                                            table.shape[0], _ptr(idx)), "pcc_gaussian_indexes")
+        return idx
+
+    def gaussian_dequant(self, sym, params, scale, bound, off_a, off_b):
+        c, n = sym.shape
+        yhat = self.empty((n, c), torch.float32)
+        check(self.lib.pcc_gaussian_dequant(self.ctx, _ptr(sym), _ptr(params), n, c, _ptr(scale), bound, off_a,
+                                            off_b, _ptr(yhat)), "pcc_gaussian_dequant")
+        return yhat
+
+    # ------------------------------------------------------------ octree (device part)
+    def octree_levels(self, keys, key_shift, depth):
+        n = keys.shape[0]
+        cap = n * depth
+        occ = self.empty((cap,), torch.uint8)
+        level_n = (C.c_int64 * depth)()
+        check(self.lib.pcc_octree_levels(self.ctx, _ptr(keys), n, key_shift, depth, _ptr(occ), cap, level_n),
+              "pcc_octree_levels")
+        ln = [int(v) for v in level_n]
+        return occ[:sum(ln)], ln
+
+
+# ---------------------------------------------------------------- host coders (no ctx)
+def rans_encode_multi(sym, idx, cdfs, sizes, offsets):
+    """sym/idx: int32 numpy [S, n]; returns list of S byte strings"""
+    lib = _abi.lib()
+    s, n = sym.shape
+    cap = 8 * n + 64
+    out = np.empty((s, cap), dtype=np.uint8)
+    lens = (C.c_int64 * s)()
+    check(lib.pcc_rans_encode_multi(_np_ptr(sym), _np_ptr(idx), n, s, _np_ptr(cdfs), cdfs.shape[1],
+                                    _np_ptr(sizes), _np_ptr(offsets), cdfs.shape[0], _np_ptr(out), cap, lens),
+          "pcc_rans_encode_multi")
+    return [out[i, :lens[i]].tobytes() for i in range(s)]
+
+
+def rans_encode(sym, idx, cdfs, sizes, offsets):
+    return rans_encode_multi(sym.reshape(1, -1), idx.reshape(1, -1), cdfs, sizes, offsets)[0]
+
+
+def rans_decode(data, idx, cdfs, sizes, offsets):
+    lib = _abi.lib()
+    n = idx.shape[0]
+    buf = np.frombuffer(data, dtype=np.uint8)
+    sym = np.empty(n, dtype=np.int32)
+    check(lib.pcc_rans_decode(_np_ptr(buf), buf.shape[0], _np_ptr(idx), n, _np_ptr(cdfs), cdfs.shape[1],
+                              _np_ptr(sizes), _np_ptr(offsets), cdfs.shape[0], _np_ptr(sym)), "pcc_rans_decode")
+    return sym
+
+
+def octree_pack(occ, level_n, n_points, origin):
+    lib = _abi.lib()
+    depth = len(level_n)
+    cap = 64 + 2 * len(occ) + 16
+    out = np.empty(cap, dtype=np.uint8)
+    ln = (C.c_int64 * max(depth, 1))(*level_n)
+    org = (C.c_int * 3)(*[int(v) for v in origin])
+    length = C.c_int64(0)
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    check(lib.pcc_octree_pack(_np_ptr(occ) if len(occ) else C.c_void_p(0), ln, depth, n_points, org,
+                              _np_ptr(out), cap, C.byref(length)), "pcc_octree_pack")
+    return out[:length.value].tobytes()
+
+
+def octree_unpack(blob):
+    lib = _abi.lib()
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    n = C.c_int64(0)
+    depth = C.c_int(0)
+    org = (C.c_int * 3)()
+    check(lib.pcc_octree_peek(_np_ptr(buf), buf.shape[0], C.byref(n), C.byref(depth), org), "pcc_octree_peek")
+    pts = np.empty((n.value, 3), dtype=np.int32)
+    if n.value:
+        check(lib.pcc_octree_unpack(_np_ptr(buf), buf.shape[0], _np_ptr(pts), n.value), "pcc_octree_unpack")
+    return pts

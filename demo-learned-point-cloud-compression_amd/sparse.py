@@ -1,0 +1,146 @@
+"""SparseTensor / CoordSet — the slice of MinkowskiEngine's tensor surface that
+the reference codec uses: ctor kwargs `coordinates, features,
+tensor_stride, device`; attributes `.C` (int32 [N,4] = b,x,y,z), `.F`
+(float32 [N,C]), `.tensor_stride`, `.device`; `.features_at_coordinates()`.
+
+Rows are stored sorted by Morton key (include/pcc.h).  A CoordSet is the
+analogue of a coordinate-map key in ME's coordinate manager: tensors that share
+coordinates share one CoordSet and therefore its cached rule books, parents and
+children.
+"""
+import numpy as np
+import torch
+
+from . import runtime as _rt
+
+
+def _log2(ts):
+    s = int(ts).bit_length() - 1
+    if ts < 1 or (1 << s) != ts:
+        raise ValueError(f"tensor_stride must be a power of two, got {ts}")
+    return s
+
+
+class CoordSet:
+    def __init__(self, rt, keys, stride, n_batch=None, offsets=None):
+        self.rt = rt
+        self.keys = keys                 # int64 tensor holding uint64 Morton keys, sorted, unique
+        self.stride = int(stride)
+        self.n = int(keys.shape[0])
+        self._coords = None
+        self._nbr27 = None
+        self._down = None                # (CoordSet, nbr8)
+        self._up = None                  # CoordSet
+        self._n_batch = n_batch
+        self._offsets = offsets          # host list, len n_batch+1
+
+    @property
+    def C(self):
+        if self._coords is None:
+            self._coords = self.rt.keys_to_coords(self.keys)
+        return self._coords
+
+    def set_batches(self, n_batch, offsets=None):
+        self._n_batch = int(n_batch)
+        self._offsets = offsets
+
+    @property
+    def n_batch(self):
+        if self._n_batch is None:
+            # batch index lives in the top 16 key bits; the last row has the largest
+            self._n_batch = (int(self.keys[-1].item()) >> 48) + 1 if self.n else 0
+        return self._n_batch
+
+    @property
+    def offsets(self):
+        """row offsets per batch index (host list of n_batch+1 ints)"""
+        if self._offsets is None:
+            self._offsets = self.rt.batch_offsets(self.keys, self.n_batch)
+        return self._offsets
+
+    def nbr27(self):
+        if self._nbr27 is None:
+            self._nbr27 = self.rt.build_map(self.keys, self.stride)
+        return self._nbr27
+
+    def down(self):
+        """parents at stride*2 and the kernel-2 rule book [8, M]"""
+        if self._down is None:
+            pkeys, nbr8 = self.rt.down_coords(self.keys, 3 * _log2(self.stride))
+            self._down = (CoordSet(self.rt, pkeys, self.stride * 2, self._n_batch), nbr8)
+        return self._down
+
+    def up(self):
+        """generative children at stride/2: 8 per row, row 8p+o"""
+        if self._up is None:
+            if self.stride < 2:
+                raise ValueError("cannot up-sample a stride-1 coordinate set")
+            ckeys = self.rt.up_coords(self.keys, 3 * (_log2(self.stride) - 1))
+            offs = [8 * o for o in self._offsets] if self._offsets is not None else None
+            self._up = CoordSet(self.rt, ckeys, self.stride // 2, self._n_batch, offs)
+        return self._up
+
+    def subset(self, rows, n_batch=None, offsets=None):
+        """stable compaction: keep `rows` (ascending uint32 indices)"""
+        return CoordSet(self.rt, self.rt.gather_rows(self.keys, rows), self.stride,
+                        n_batch if n_batch is not None else self._n_batch, offsets)
+
+
+class SparseTensor:
+    """ME.SparseTensor-shaped.  `coordinates` may be a float or int tensor /
+    array [N,4] (b,x,y,z); floats are floored like ME does (the reference
+    passes float coordinates, codec_pipeline.py:259-266)."""
+
+    def __init__(self, features=None, coordinates=None, tensor_stride=1, device=None, coordset=None, rt=None):
+        rt = rt if rt is not None else (coordset.rt if coordset is not None else _rt.current())
+        self.rt = rt
+        if coordset is not None:
+            self.cs = coordset
+            self.F = features
+            return
+        ts = tensor_stride[0] if isinstance(tensor_stride, (list, tuple)) else int(tensor_stride)
+        _log2(ts)
+        coords = coordinates
+        if isinstance(coords, np.ndarray):
+            coords = torch.from_numpy(np.ascontiguousarray(coords))
+        if coords.dtype.is_floating_point:
+            coords = torch.floor(coords)
+        coords = rt.to_device(coords, torch.int32)
+        feats = rt.to_device(features, torch.float32)
+        if coords.ndim != 2 or coords.shape[1] != 4 or feats.shape[0] != coords.shape[0]:
+            raise ValueError(f"coordinates must be [N,4] and match features, got {tuple(coords.shape)} / "
+                             f"{tuple(feats.shape)}")
+        keys = rt.morton_keys(coords)            # raises PccError(RANGE) on out-of-range input
+        perm = rt.sort_pairs(keys)               # keys sorted in place
+        if not rt.check_unique(keys):
+            raise _rt.PccError(-4, "SparseTensor", "duplicate coordinates")
+        self.cs = CoordSet(rt, keys, ts)
+        self.F = rt.gather_rows(feats, perm)
+
+    # --- ME surface -----------------------------------------------------
+    @property
+    def C(self):
+        return self.cs.C
+
+    @property
+    def tensor_stride(self):
+        return [self.cs.stride] * 3
+
+    @property
+    def device(self):
+        return self.rt.device
+
+    @property
+    def shape(self):
+        return self.F.shape
+
+    def features_at_coordinates(self, query):
+        """exact-lattice lookup, zeros where the coordinate is absent
+        (codec_pipeline.py:401, codec_parallel.py:387).  query: [M,4] float/int."""
+        q = query
+        if q.dtype.is_floating_point:
+            q = torch.floor(q)
+        q = self.rt.to_device(q, torch.int32)
+        qkeys = self.rt.morton_keys(q)
+        rows = self.rt.lookup(self.cs.keys, qkeys)
+        return self.rt.gather_rows_or_zero(self.F, rows)

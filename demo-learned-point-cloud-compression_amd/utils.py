@@ -1,0 +1,134 @@
+"""Codec helpers with the names and meaning of the reference's shared/utils.py
+(stack_tensors :10, get_points_per_batch :60, get_features_per_batch :87,
+sort_tensor :116, sort_points :145, gpcc_encode :169, gpcc_decode :210),
+implemented on the C-ABI.
+
+Canonical order = ascending key b*1e15 + x*1e10 + y*1e5 + z (int64), exactly
+the reference's sortable value; SparseTensor rows themselves stay in Morton
+order, so sort_tensor returns a row view (coordinates + features in canonical
+order) instead of re-building a tensor.
+"""
+import numpy as np
+import torch
+
+from . import runtime as _rt
+from .sparse import SparseTensor
+
+
+def stack_tensors(points, colors=None):
+    """list of [N_i,3] -> [sum N_i, 4] with the batch index prepended
+    (shared/utils.py:10-42).  Accepts numpy arrays or torch tensors; the result
+    lives where the inputs live."""
+    pts = [torch.from_numpy(np.ascontiguousarray(p)) if isinstance(p, np.ndarray) else p for p in points]
+    if len(pts) == 0:
+        stacked = torch.zeros((0, 4), dtype=torch.int32)
+    else:
+        stacked = torch.cat([torch.cat((torch.full((p.shape[0], 1), i, dtype=p.dtype, device=p.device), p), dim=1)
+                             for i, p in enumerate(pts)], dim=0)
+    if colors is None:
+        return stacked
+    cols = [torch.from_numpy(np.ascontiguousarray(c)) if isinstance(c, np.ndarray) else c for c in colors]
+    stacked_colors = torch.cat(cols, dim=0) if cols else torch.zeros((0, 3))
+    return stacked, stacked_colors
+
+
+class RowView:
+    """coordinates / features of a sparse tensor in canonical order"""
+
+    def __init__(self, coords, feats, stride, perm=None):
+        self.C = coords
+        self.F = feats
+        self.tensor_stride = [stride] * 3
+        self.perm = perm
+
+
+def sort_points(points):
+    """[N,4] coordinates -> the same rows in canonical order (shared/utils.py:145-165)"""
+    rt = _rt.current()
+    pts = points
+    if pts.dtype.is_floating_point:
+        pts = torch.floor(pts)
+    pts = rt.to_device(pts, torch.int32)
+    perm = rt.sort_coords(pts)
+    return rt.gather_rows(pts, perm)
+
+
+def sort_tensor(sparse_tensor):
+    """canonical-order view of a tensor (shared/utils.py:116-141)"""
+    rt = sparse_tensor.rt
+    coords = sparse_tensor.C
+    perm = rt.sort_coords(coords)
+    feats = rt.gather_rows(sparse_tensor.F, perm) if sparse_tensor.F is not None else None
+    return RowView(rt.gather_rows(coords, perm), feats, sparse_tensor.cs.stride, perm)
+
+
+def _split_offsets(coords_host):
+    b = coords_host[:, 0]
+    ids = np.unique(b)
+    return [(int(i), np.nonzero(b == i)[0]) for i in ids]
+
+
+def get_points_per_batch(sparse_tensor, batch_dim=True):
+    """list of per-frame coordinate blocks (shared/utils.py:60-85)"""
+    coords = sparse_tensor.C if hasattr(sparse_tensor, "C") else sparse_tensor
+    host = coords.cpu().numpy()
+    out = []
+    for _, rows in _split_offsets(host):
+        blk = coords[torch.from_numpy(rows).to(coords.device)]
+        out.append(blk[:, 1:] if batch_dim else blk)
+    return out
+
+
+def get_features_per_batch(features, coordinates=None):
+    """list of per-frame feature blocks (shared/utils.py:87-114)"""
+    if coordinates is None:
+        coordinates = features.C
+        features = features.F
+    elif hasattr(features, "F"):
+        raise ValueError("Not defined for torch features and no coordinates.")
+    host = coordinates.cpu().numpy()
+    return [features[torch.from_numpy(rows).to(features.device)] for _, rows in _split_offsets(host)]
+
+
+# --------------------------------------------------------------- geometry slot
+def octree_depth_origin(first_key, last_key, key_shift):
+    """root cube of one frame from its first / last Morton key (python ints):
+    depth = floor(msb(first ^ last) / 3) + 1 in lattice units (min 1),
+    origin = corner of the aligned cube, in lattice units"""
+    mask48 = (1 << 48) - 1
+    a = (first_key & mask48) >> key_shift
+    b = (last_key & mask48) >> key_shift
+    diff = a ^ b
+    depth = 1 if diff == 0 else (diff.bit_length() - 1) // 3 + 1
+    corner = (a >> (3 * depth)) << (3 * depth)
+    bias = 32768 >> (key_shift // 3)
+
+    def compact(v):
+        r = 0
+        for i in range(16):
+            r |= ((v >> (3 * i)) & 1) << i
+        return r
+
+    origin = [compact(corner >> 2) - bias, compact(corner >> 1) - bias, compact(corner) - bias]
+    return depth, origin
+
+
+def gpcc_encode(keys_dev, keys_host, lo, hi, key_shift):
+    """Lossless geometry blob for rows [lo,hi) of a Morton-sorted key array.
+    Stands in for utils.gpcc_encode (shared/utils.py:169-207): the reference
+    writes an ASCII PLY of `points/8` and shells out to tmc3; here the device
+    builds the octree occupancy bytes and the host entropy-codes them."""
+    rt = _rt.current()
+    n = hi - lo
+    if n == 0:
+        return _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
+    first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
+    depth, origin = octree_depth_origin(first, last, key_shift)
+    occ, level_n = rt.octree_levels(keys_dev[lo:hi], key_shift, depth)
+    return _rt.octree_pack(occ.cpu().numpy(), level_n, n, origin)
+
+
+def gpcc_decode(data, scale=8):
+    """blob -> int32 [n,3] coordinates (lattice units * scale), Morton order.
+    Stands in for utils.gpcc_decode (shared/utils.py:210-240; `* 8` at :235)."""
+    return _rt.octree_unpack(data) * np.int32(scale)

@@ -1,0 +1,267 @@
+/*
+ * pcc.h — C-ABI of libpcc_hip.so, the MI355X (gfx950) codec hot path.
+ *
+ * This is the drop-in boundary for the path
+ *     CompressionPipeline.compress()    sender/encoder/codec_pipeline.py:196
+ *     DecompressionPipeline.decompress() receiver/decoder/codec_parallel.py:141
+ * of ikt-luh/Demo-Learned-Point-Cloud-Compression.  In the reference that path
+ * crosses into native code through four third-party bindings that are NOT in
+ * the reference tree (MinkowskiEngine pybind, CompressAI's rANS pybind, the
+ * tmc3 subprocess, the `bitstream` Cython module).
+ * Each entry point below names the reference call site it serves.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures;
+ *   - `d_` prefix  = pointer into device (HBM) memory, `h_` = host memory;
+ *   - every device op is enqueued on the ctx stream and is asynchronous unless
+ *     it returns a count through a host pointer (then it synchronises the
+ *     stream once before returning);
+ *   - return value: 0 = ok, negative = error (pcc_last_error() has the text);
+ *     the library never throws across the ABI;
+ *   - caller owns inputs and outputs; scratch comes from a ctx-owned arena
+ *     that is valid until the next call on the same ctx;
+ *   - one ctx per in-flight compress()/decompress() call ("slot"): the
+ *     reference runs up to 3 concurrent calls (sender/encoder/encoder.py:50).
+ *
+ * Data layout (HBM)
+ *   coords  int32 [N,4]  rows (b,x,y,z), coordinates multiples of the tensor
+ *                        stride, each in [-32768,32767], b in [0,65535]
+ *   keys    uint64 [N]   Morton key: b<<48 | interleave(x+32768,y+32768,z+32768)
+ *                        (x is the top bit of each triple).  Rows of every
+ *                        sparse tensor are kept sorted by this key.
+ *   feats   float32 [N,C] row-major
+ *   nbr     int32 [K,N]  rule book, out-stationary: nbr[k*N+n] = input row
+ *                        feeding output row n through kernel offset k, -1 if
+ *                        absent.  3^3: k=(dx+1)*9+(dy+1)*3+(dz+1); 2^3: k=octant
+ *                        = xbit<<2|ybit<<1|zbit.
+ *   weights float32 [K,Cin,Cout], bias float32 [Cout]
+ *
+ * Arithmetic contract (what the parity tests check bit-for-bit)
+ *   out[n][co] = bias[co]; for k ascending (present neighbours only), for ci
+ *   ascending: out = fmaf(in[nbr[k][n]][ci], W[k][ci][co], out); then ReLU if
+ *   asked.  Evaluated with v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf
+ *   chain) or scalar fmaf; never atomics.
+ */
+#ifndef PCC_H
+#define PCC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCC_ABI_VERSION 1
+
+/* error codes */
+#define PCC_OK 0
+#define PCC_E_ARG (-1)      /* bad argument / unsupported shape            */
+#define PCC_E_HIP (-2)      /* HIP runtime error                           */
+#define PCC_E_RANGE (-3)    /* coordinate / batch index out of range       */
+#define PCC_E_DUP (-4)      /* duplicate coordinates in input              */
+#define PCC_E_STREAM (-5)   /* corrupt or truncated bitstream              */
+#define PCC_E_NOMEM (-6)
+
+typedef struct pcc_ctx pcc_ctx;
+
+int pcc_abi_version(void);
+const char* pcc_last_error(void);
+
+/* ctx = device + stream + scratch arena.  `stream` is a hipStream_t passed as
+ * void* (NULL = default stream). */
+pcc_ctx* pcc_create(int device, void* stream);
+void pcc_destroy(pcc_ctx* ctx);
+int pcc_set_stream(pcc_ctx* ctx, void* stream);
+int pcc_sync(pcc_ctx* ctx);
+/* start/stop a hipEvent pair on the ctx stream; elapsed returns ms of the last
+ * completed pair (used by bench.py for the per-kernel roofline figure). */
+int pcc_timer_start(pcc_ctx* ctx);
+int pcc_timer_stop(pcc_ctx* ctx);
+int pcc_timer_elapsed_ms(pcc_ctx* ctx, float* h_ms);
+
+/* ---- coordinate keys and ordering ------------------------------------- */
+
+/* replaces: MinkowskiEngine coordinate-map insertion inside every
+ * ME.SparseTensor(...) ctor (codec_pipeline.py:262,308; codec_parallel.py:296,
+ * 309,411).  d_flag (int32[1], device) is OR-ed with 1 if any coordinate is
+ * out of range. */
+int pcc_morton_keys(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
+                    uint64_t* d_keys, int32_t* d_flag);
+/* inverse: keys -> (b,x,y,z) */
+int pcc_keys_to_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                       int32_t* d_coords);
+/* replaces: the sortable value of shared/utils.py:131-132 / :160-161
+ * (key = b*1e15 + x*1e10 + y*1e5 + z, int64) */
+int pcc_linear_keys(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
+                    int64_t* d_keys);
+/* stable LSD radix sort of 64-bit keys (unsigned order; pass is_signed=1 for
+ * int64 order) carrying the original row index.  d_keys is sorted in place,
+ * d_perm[i] = original index of the i-th smallest key. */
+int pcc_sort_pairs(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
+                   int is_signed);
+/* replaces: utils.sort_tensor / utils.sort_points (shared/utils.py:116-165):
+ * d_perm = argsort of the linear key. */
+int pcc_sort_coords(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
+                    uint32_t* d_perm);
+/* dst[i,:] = src[perm[i],:], rows of row_bytes (multiple of 4) */
+int pcc_gather_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* d_perm,
+                    int64_t n, int row_bytes, void* d_dst);
+/* h_dup = 1 if two adjacent sorted keys are equal */
+int pcc_check_unique(pcc_ctx* ctx, const uint64_t* d_sorted_keys, int64_t n,
+                     int* h_dup);
+/* per-batch row offsets of a key-sorted tensor: h_offsets[b] = first row with
+ * batch >= b, for b in [0, n_batch]; (h_offsets[n_batch] == n) */
+int pcc_batch_offsets(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                      int n_batch, int64_t* h_offsets);
+
+/* ---- coordinate pyramid ------------------------------------------------ */
+
+/* replaces: the output coordinate map of every stride-2 kernel-2 convolution
+ * (g_a / h_a down stages, g_s.down_conv codec_parallel.py:302-303):
+ * parents = unique(floor(c / 2ts) * 2ts).  child_shift = 3*log2(ts).
+ * Outputs sized for n rows (upper bound): d_pkeys, d_nbr8 ([8,n_cap] with
+ * row pitch n_cap; only the first *h_n_out columns are meaningful).
+ * Synchronises to return *h_n_out. */
+int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                    int child_shift, uint64_t* d_pkeys, int32_t* d_nbr8,
+                    int64_t n_cap, int64_t* h_n_out);
+/* replaces: the generative transposed-convolution coordinate map (up stages
+ * of h_s and g_s): children key = parent | o << (3*log2(ts/2)), row 8p+o. */
+int pcc_up_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                  int child_shift, uint64_t* d_ckeys);
+
+/* ---- rule book (kernel map) and lookup --------------------------------- */
+
+/* replaces: ME kernel-map generation for 3^3 stride-1 convolutions.
+ * stride = tensor stride ts; d_nbr is [27, n]. */
+int pcc_build_map(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int stride,
+                  int32_t* d_nbr);
+/* replaces: SparseTensor.features_at_coordinates (codec_pipeline.py:401,
+ * codec_parallel.py:387) — exact-lattice lookup; d_rows[i] = row of query i in
+ * the key set or -1. */
+int pcc_lookup(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+               const uint64_t* d_qkeys, int64_t m, int32_t* d_rows);
+/* dst[i,:] = rows[i] >= 0 ? src[rows[i],:] : 0 */
+int pcc_gather_rows_or_zero(pcc_ctx* ctx, const float* d_src,
+                            const int32_t* d_rows, int64_t m, int c,
+                            float* d_dst);
+
+/* ---- sparse network layers -------------------------------------------- */
+
+/* replaces: MinkowskiConvolution forward (3^3 stride 1 with K=27 and a rule
+ * book from pcc_build_map; 2^3 stride 2 with K=8 and the rule book from
+ * pcc_down_coords).  Supported (cin,cout): (4,32) (32,32) (32,64) on the MFMA
+ * path, any (cin<=64, cout<=64) on the scalar-fmaf path (same results). */
+int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
+                    const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
+                    int64_t n_out, const float* d_w, const float* d_bias,
+                    int cin, int cout, int relu, float* d_out);
+/* replaces: MinkowskiGenerativeConvolutionTranspose forward (kernel 2,
+ * stride 2): out[8p+o] = W[o]^T in[p] + bias. */
+int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in,
+                  const float* d_w, const float* d_bias, int cin, int cout,
+                  int relu, float* d_out);
+/* 1x1 convolution (MinkowskiLinear / kernel-1 conv): occupancy and colour
+ * heads of g_s. */
+int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const float* d_w,
+               const float* d_bias, int cin, int cout, int relu, float* d_out);
+
+/* replaces: the per-frame top-k occupancy pruning inside model.g_s(y_hat,k=ks)
+ * (codec_parallel.py:469): within each batch segment keep the k[b] rows with
+ * the largest logit (ties: lower row first).  d_keep_rows receives the kept
+ * row indices in ascending order; *h_n_keep their number.  h_offsets as from
+ * pcc_batch_offsets (n_batch+1 entries), h_k n_batch entries. */
+int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, int n_batch,
+                   const int64_t* h_offsets, const int64_t* h_k,
+                   uint32_t* d_keep_rows, int64_t* h_n_keep);
+
+/* ---- entropy-model device kernels ------------------------------------- */
+
+/* replaces: EntropyBottleneck.compress symbol formation + dequantised z_hat
+ * (codec_pipeline.py:303-306): sym[c*n+i] = rint(z[i][c] - med[c]) (int32,
+ * channel-major), zhat[i][c] = sym + med[c]. */
+int pcc_factorized_quant(pcc_ctx* ctx, const float* d_z, int64_t n, int c,
+                         const float* d_med, int32_t* d_sym, float* d_zhat);
+/* decoder side: zhat[i][c] = sym[c*n+i] + med[c] (codec_parallel.py:307-314) */
+int pcc_factorized_dequant(pcc_ctx* ctx, const int32_t* d_sym, int64_t n,
+                           int c, const float* d_med, float* d_zhat);
+/* replaces: build_indexes + quantize of GaussianConditional.compress for Q
+ * quality settings at once (codec_pipeline.py:407-430).
+ *   params [n, 2c] = (scales_hat | means_hat) rows aligned with y rows
+ *   scale  [q, c]  = scale_nn(q)+eps per quality
+ *   table  [n_tab] ascending scale table (n_tab <= 64)
+ *   sym,idx int32 [q, c, n] channel-major
+ * sym = rint(y*s - mean*s), idx = (n_tab-1) - #{t in table[:-1] : max(sc*s,
+ * table[0]) <= t}. */
+int pcc_gaussian_quant(pcc_ctx* ctx, const float* d_y, const float* d_params,
+                       int64_t n, int c, const float* d_scale, int q,
+                       const float* d_table, int n_tab, int32_t* d_sym,
+                       int32_t* d_idx);
+/* decoder side (codec_parallel.py:394-409): indexes for one quality */
+int pcc_gaussian_indexes(pcc_ctx* ctx, const float* d_params, int64_t n, int c,
+                         const float* d_scale, const float* d_table, int n_tab,
+                         int32_t* d_idx);
+/* decoder side de-quantisation with offsets (codec_parallel.py:401-409):
+ *   sigma = max(sc*s, bound); off = -(a / (b + sigma)), 0 where sym == 0
+ *   yhat = sign(sym) * (|sym| + off) * (1/s) + mean */
+int pcc_gaussian_dequant(pcc_ctx* ctx, const int32_t* d_sym,
+                         const float* d_params, int64_t n, int c,
+                         const float* d_scale, float bound, float off_a,
+                         float off_b, float* d_yhat);
+
+/* ---- host coders (no GPU needed) --------------------------------------- */
+
+/* replaces: compressai.ans.RansEncoder.encode_with_indexes / RansDecoder.
+ * decode_with_indexes (CompressAI 1.2.4, called from entropy_bottleneck /
+ * gaussian_conditional .compress/.decompress: codec_pipeline.py:305-306,
+ * 426-430; codec_parallel.py:307,400).
+ *   cdfs   int32 [n_cdf, cdf_pitch] quantised CDFs (16-bit precision)
+ *   sizes  int32 [n_cdf] cdf lengths, offsets int32 [n_cdf]
+ * encode: returns bytes written into h_out (cap bytes) via *h_len. */
+int pcc_rans_encode(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
+                    const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                    const int32_t* h_offsets, int n_cdf, uint8_t* h_out,
+                    int64_t cap, int64_t* h_len);
+int pcc_rans_decode(const uint8_t* h_in, int64_t len, const int32_t* h_idx,
+                    int64_t n, const int32_t* h_cdfs, int cdf_pitch,
+                    const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                    int32_t* h_sym);
+/* the same for n_streams independent streams coded on n_streams host threads
+ * (the Q quality settings of gaussian_model_step_batched). */
+int pcc_rans_encode_multi(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
+                          int n_streams, const int32_t* h_cdfs, int cdf_pitch,
+                          const int32_t* h_sizes, const int32_t* h_offsets,
+                          int n_cdf, uint8_t* h_out, int64_t cap_each,
+                          int64_t* h_lens);
+
+/* replaces: utils.gpcc_encode / gpcc_decode (shared/utils.py:169-240), i.e.
+ * the tmc3 subprocess: lossless octree occupancy coding of one frame's latent
+ * coordinates.  The blob is opaque to the container (length-prefixed slot) and
+ * is NOT tmc3-compatible.
+ * Device part: occupancy bytes of every octree level of one frame.
+ *   d_keys    the frame's rows of a Morton-sorted key array (stride-ts tensor)
+ *   key_shift 3*log2(ts): leaf = (key >> key_shift) & (2^(3*depth) - 1)
+ *   depth     log2 of the side of the aligned root cube (host computes it from
+ *             the first and last key: floor(msb(first^last)/3)+1, min 1)
+ *   d_occ     uint8  [sum of level node counts], root level first
+ *   h_level_n int64  [depth] nodes per level (root first)
+ * cap = capacity of d_occ in bytes (n*depth is always enough). */
+int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                      int key_shift, int depth, uint8_t* d_occ, int64_t cap,
+                      int64_t* h_level_n);
+/* host part: adaptive binary range-ANS of the occupancy bytes */
+int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, int depth,
+                    int64_t n_points, const int32_t* h_origin, uint8_t* h_out,
+                    int64_t cap, int64_t* h_len);
+/* parse blob header: n_points, depth, origin[3] */
+int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points,
+                    int* h_depth, int32_t* h_origin);
+/* decode blob to Morton-ordered points int32 [n_points,3] (origin added) */
+int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_points,
+                      int64_t cap_points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_H */

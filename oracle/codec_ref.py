@@ -1,0 +1,413 @@
+"""codec_ref.py — CPU restatement of compress()/decompress() (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; the product package never does.  It restates the stage
+order, tensor layouts, coding order and byte container of
+    sender/encoder/codec_pipeline.py:196-517   (compress and its stages)
+    receiver/decoder/codec_parallel.py:141-502 (decompress and its stages)
+    shared/utils.py:10-240                     (stacking, canonical sort, geometry slot)
+on numpy arrays, calling the plain-C kernels of oracle/pcc_oracle.c for the
+arithmetic.  PARITY UNPINNED: see the header of pcc_oracle.c — the reference
+has no golden vectors for this path and its native dependencies are absent.
+
+The model architecture and weights come from the same checkpoint file the
+product loads (tools/make_checkpoint.py); the checkpoint is data, not code.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+_CKPT = os.path.join(os.path.dirname(_HERE), "demo-learned-point-cloud-compression_amd", "assets",
+                     "demo_small.npz")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, ckpt=_CKPT, threads=None):
+        if not os.path.exists(_LIB):
+            build()
+        if threads is not None:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+        self.lib = C.CDLL(_LIB)
+        self.lib.orc_down_coords.restype = C.c_int64
+        self.lib.orc_topk.restype = C.c_int64
+        self.lib.orc_rans_encode.restype = C.c_int64
+        self.lib.orc_octree_encode.restype = C.c_int64
+        self.lib.orc_octree_decode.restype = C.c_int64
+        with np.load(ckpt) as f:
+            self.t = {k: f[k] for k in f.files}
+        self.eps = np.float32(self.t["entropy_model.eps"])
+        self.off_a, self.off_b = [np.float32(v) for v in self.t["entropy_model.offsets_ab"]]
+
+    # ------------------------------------------------------------ keys
+    def morton_keys(self, coords):
+        coords = np.ascontiguousarray(coords, dtype=np.int32)
+        keys = np.empty(coords.shape[0], dtype=np.uint64)
+        self.lib.orc_morton_keys(_p(coords), C.c_int64(coords.shape[0]), _p(keys))
+        return keys
+
+    def keys_to_coords(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        coords = np.empty((keys.shape[0], 4), dtype=np.int32)
+        self.lib.orc_keys_to_coords(_p(keys), C.c_int64(keys.shape[0]), _p(coords))
+        return coords
+
+    def linear_keys(self, coords):
+        coords = np.ascontiguousarray(coords, dtype=np.int32)
+        keys = np.empty(coords.shape[0], dtype=np.int64)
+        self.lib.orc_linear_keys(_p(coords), C.c_int64(coords.shape[0]), _p(keys))
+        return keys
+
+    def canonical_perm(self, coords):
+        """argsort of the reference's sortable value (shared/utils.py:131-133)"""
+        return np.argsort(self.linear_keys(coords), kind="stable")
+
+    def sparse_tensor(self, coords, feats):
+        """ME.SparseTensor ctor: rows re-ordered by Morton key"""
+        keys = self.morton_keys(coords)
+        perm = np.argsort(keys, kind="stable")
+        return keys[perm], np.ascontiguousarray(np.asarray(feats, dtype=np.float32)[perm])
+
+    # ------------------------------------------------------------ maps
+    def down(self, keys, stride):
+        n = keys.shape[0]
+        shift = 3 * (int(stride).bit_length() - 1)
+        pkeys = np.empty(n, dtype=np.uint64)
+        tmp = np.empty((8, max(n, 1)), dtype=np.int32)
+        m = self.lib.orc_down_coords(_p(keys), C.c_int64(n), C.c_int(shift), _p(pkeys), _p(tmp))
+        return pkeys[:m].copy(), np.ascontiguousarray(tmp[:, :m])
+
+    def up(self, keys, stride):
+        shift = 3 * (int(stride).bit_length() - 2)
+        ck = np.empty(8 * keys.shape[0], dtype=np.uint64)
+        self.lib.orc_up_coords(_p(keys), C.c_int64(keys.shape[0]), C.c_int(shift), _p(ck))
+        return ck
+
+    def map27(self, keys, stride):
+        nbr = np.empty((27, keys.shape[0]), dtype=np.int32)
+        self.lib.orc_build_map27(_p(keys), C.c_int64(keys.shape[0]), C.c_int(stride), _p(nbr))
+        return nbr
+
+    def lookup(self, keys, qkeys):
+        rows = np.empty(qkeys.shape[0], dtype=np.int32)
+        self.lib.orc_lookup(_p(keys), C.c_int64(keys.shape[0]), _p(qkeys), C.c_int64(qkeys.shape[0]), _p(rows))
+        return rows
+
+    # ------------------------------------------------------------ layers
+    def sparse_conv(self, x, nbr, w, b, relu):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        k, n_out = nbr.shape
+        cin, cout = w.shape[1], w.shape[2]
+        out = np.empty((n_out, cout), dtype=np.float32)
+        self.lib.orc_sparse_conv(_p(x), _p(nbr), C.c_int(k), C.c_int64(n_out), C.c_int64(n_out), _p(w), _p(b),
+                                 C.c_int(cin), C.c_int(cout), C.c_int(int(relu)), _p(out))
+        return out
+
+    def convT(self, x, w, b, relu):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        cin, cout = w.shape[1], w.shape[2]
+        out = np.empty((8 * x.shape[0], cout), dtype=np.float32)
+        self.lib.orc_convT_gen(_p(x), C.c_int64(x.shape[0]), _p(w), _p(b), C.c_int(cin), C.c_int(cout),
+                               C.c_int(int(relu)), _p(out))
+        return out
+
+    def linear(self, x, w, b, relu=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        cin, cout = w.shape
+        out = np.empty((x.shape[0], cout), dtype=np.float32)
+        self.lib.orc_linear(_p(x), C.c_int64(x.shape[0]), _p(np.ascontiguousarray(w)), _p(b), C.c_int(cin),
+                            C.c_int(cout), C.c_int(int(relu)), _p(out))
+        return out
+
+    def wb(self, name):
+        return np.ascontiguousarray(self.t[name + ".weight"]), np.ascontiguousarray(self.t[name + ".bias"])
+
+    def topk(self, logits, offsets, k):
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        offs = np.asarray(offsets, dtype=np.int64)
+        ks = np.asarray(k, dtype=np.int64)
+        keep = np.empty(logits.shape[0], dtype=np.uint32)
+        nk = self.lib.orc_topk(_p(logits), C.c_int64(logits.shape[0]), C.c_int(len(k)), _p(offs), _p(ks), _p(keep))
+        return keep[:nk].copy()
+
+    # ------------------------------------------------------------ entropy
+    def factorized_quant(self, z):
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        n, c = z.shape
+        med = np.ascontiguousarray(self.t["entropy_bottleneck.medians"], dtype=np.float32)
+        sym = np.empty((c, n), dtype=np.int32)
+        zhat = np.empty((n, c), dtype=np.float32)
+        self.lib.orc_factorized_quant(_p(z), C.c_int64(n), C.c_int(c), _p(med), _p(sym), _p(zhat))
+        return sym, zhat
+
+    def factorized_dequant(self, sym):
+        c, n = sym.shape
+        med = np.ascontiguousarray(self.t["entropy_bottleneck.medians"], dtype=np.float32)
+        zhat = np.empty((n, c), dtype=np.float32)
+        self.lib.orc_factorized_dequant(_p(np.ascontiguousarray(sym)), C.c_int64(n), C.c_int(c), _p(med), _p(zhat))
+        return zhat
+
+    def gaussian_quant(self, y, params, scale):
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        scale = np.ascontiguousarray(scale, dtype=np.float32)
+        n, c = y.shape
+        q = scale.shape[0]
+        tab = np.ascontiguousarray(self.t["gaussian_conditional.scale_table"], dtype=np.float32)
+        sym = np.empty((q, c, n), dtype=np.int32)
+        idx = np.empty((q, c, n), dtype=np.int32)
+        self.lib.orc_gaussian_quant(_p(y), _p(params), C.c_int64(n), C.c_int(c), _p(scale), C.c_int(q), _p(tab),
+                                    C.c_int(tab.shape[0]), _p(sym), _p(idx))
+        return sym, idx
+
+    def gaussian_indexes(self, params, scale):
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        n, c = params.shape[0], params.shape[1] // 2
+        tab = np.ascontiguousarray(self.t["gaussian_conditional.scale_table"], dtype=np.float32)
+        idx = np.empty((c, n), dtype=np.int32)
+        self.lib.orc_gaussian_indexes(_p(params), C.c_int64(n), C.c_int(c),
+                                      _p(np.ascontiguousarray(scale, dtype=np.float32)), _p(tab),
+                                      C.c_int(tab.shape[0]), _p(idx))
+        return idx
+
+    def gaussian_dequant(self, sym, params, scale):
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        c, n = sym.shape
+        tab = self.t["gaussian_conditional.scale_table"]
+        yhat = np.empty((n, c), dtype=np.float32)
+        self.lib.orc_gaussian_dequant(_p(np.ascontiguousarray(sym, dtype=np.int32)), _p(params), C.c_int64(n),
+                                      C.c_int(c), _p(np.ascontiguousarray(scale, dtype=np.float32)),
+                                      C.c_float(float(tab[0])), C.c_float(float(self.off_a)),
+                                      C.c_float(float(self.off_b)), _p(yhat))
+        return yhat
+
+    def _tables(self, which):
+        cdf = np.ascontiguousarray(self.t[which + ".quantized_cdf"], dtype=np.int32)
+        return (cdf, np.ascontiguousarray(self.t[which + ".cdf_length"], dtype=np.int32),
+                np.ascontiguousarray(self.t[which + ".offset"], dtype=np.int32))
+
+    def rans_encode(self, sym, idx, which):
+        cdf, sizes, offs = self._tables(which)
+        sym = np.ascontiguousarray(sym, dtype=np.int32).reshape(-1)
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1)
+        cap = 8 * sym.shape[0] + 64
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.lib.orc_rans_encode(_p(sym), _p(idx), C.c_int64(sym.shape[0]), _p(cdf), C.c_int(cdf.shape[1]),
+                                     _p(sizes), _p(offs), _p(out), C.c_int64(cap))
+        assert n >= 0
+        return out[:n].tobytes()
+
+    def rans_decode(self, data, idx, which):
+        cdf, sizes, offs = self._tables(which)
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        sym = np.empty(idx.shape[0], dtype=np.int32)
+        r = self.lib.orc_rans_decode(_p(buf), C.c_int64(buf.shape[0]), _p(idx), C.c_int64(idx.shape[0]), _p(cdf),
+                                     C.c_int(cdf.shape[1]), _p(sizes), _p(offs), _p(sym))
+        assert r == 0, r
+        return sym
+
+    def octree_encode(self, points, bias):
+        points = np.ascontiguousarray(points, dtype=np.int32)
+        cap = 64 + 16 * points.shape[0] * 2 + 64
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.lib.orc_octree_encode(_p(points), C.c_int64(points.shape[0]), C.c_int(bias), _p(out), C.c_int64(cap))
+        assert n >= 0
+        return out[:n].tobytes()
+
+    def octree_decode(self, blob):
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        n = struct.unpack_from("<I", blob, 4)[0]
+        pts = np.empty((max(n, 1), 3), dtype=np.int32)
+        r = self.lib.orc_octree_decode(_p(buf), C.c_int64(buf.shape[0]), _p(pts), C.c_int64(n))
+        assert r == n, (r, n)
+        return pts[:n]
+
+    # ------------------------------------------------------------ model
+    def scale_nn(self, q):
+        """scale = 0.5 + |relu(q W0 + b0) W1 + b1| in float32, fixed order"""
+        t = self.t
+        q = np.asarray(q, dtype=np.float32).reshape(-1, 2)
+        out = np.empty((q.shape[0], t["scale_nn.l1.weight"].shape[1]), dtype=np.float32)
+        for r in range(q.shape[0]):
+            h = t["scale_nn.l0.bias"].astype(np.float32).copy()
+            for i in range(2):
+                h = (h + q[r, i] * t["scale_nn.l0.weight"][i]).astype(np.float32)
+            h = np.maximum(h, np.float32(0))
+            o = t["scale_nn.l1.bias"].astype(np.float32).copy()
+            for i in range(h.shape[0]):
+                o = (o + h[i] * t["scale_nn.l1.weight"][i]).astype(np.float32)
+            out[r] = np.float32(0.5) + np.abs(o)
+        return out
+
+    @staticmethod
+    def batch_offsets(keys, n_batch):
+        b = (keys >> np.uint64(48)).astype(np.int64)
+        return [int(np.searchsorted(b, i, side="left")) for i in range(n_batch)] + [int(keys.shape[0])]
+
+    def g_a(self, keys, feats, n_batch):
+        counts = []
+        stride = 1
+        for j in range(3):
+            offs = self.batch_offsets(keys, n_batch)
+            counts.append([offs[i + 1] - offs[i] for i in range(n_batch)])
+            feats = self.sparse_conv(feats, self.map27(keys, stride), *self.wb(f"g_a.conv{j}"), True)
+            pkeys, nbr8 = self.down(keys, stride)
+            feats = self.sparse_conv(feats, nbr8, *self.wb(f"g_a.down{j}"), True)
+            keys, stride = pkeys, stride * 2
+        y = self.sparse_conv(feats, self.map27(keys, stride), *self.wb("g_a.conv3"), False)
+        return keys, y, [counts[2], counts[1], counts[0]]
+
+    def h_a(self, keys, y):
+        h = self.sparse_conv(y, self.map27(keys, 8), *self.wb("h_a.conv0"), True)
+        k16, nbr8 = self.down(keys, 8)
+        h = self.sparse_conv(h, nbr8, *self.wb("h_a.down0"), True)
+        k32, nbr8 = self.down(k16, 16)
+        return k32, self.sparse_conv(h, nbr8, *self.wb("h_a.down1"), False)
+
+    def h_s(self, keys32, zhat):
+        h = self.convT(zhat, *self.wb("h_s.up0"), True)
+        k16 = self.up(keys32, 32)
+        h = self.convT(h, *self.wb("h_s.up1"), True)
+        k8 = self.up(k16, 16)
+        return k8, self.sparse_conv(h, self.map27(k8, 8), *self.wb("h_s.conv0"), False)
+
+    def g_s(self, keys, yhat, ks, n_batch):
+        h, stride = yhat, 8
+        offs = self.batch_offsets(keys, n_batch)
+        for j in range(3):
+            h = self.convT(h, *self.wb(f"g_s.up{j}"), True)
+            keys = self.up(keys, stride)
+            stride //= 2
+            offs = [8 * o for o in offs]
+            h = self.sparse_conv(h, self.map27(keys, stride), *self.wb(f"g_s.conv{j}"), True)
+            w, b = self.wb(f"g_s.occ{j}")
+            logits = self.linear(h, w, b)[:, 0]
+            kj = [min(int(ks[j][f]), offs[f + 1] - offs[f]) for f in range(n_batch)]
+            keep = self.topk(logits, offs, kj)
+            keys, h = keys[keep], h[keep]
+            offs = [0]
+            for v in kj:
+                offs.append(offs[-1] + v)
+        w, b = self.wb("g_s.color")
+        return keys, self.linear(h, w, b), offs
+
+    # ------------------------------------------------------------ pipeline
+    def compress(self, frames, settings):
+        """frames: list of {"points": int[N,3], "colors": float[N,3]} -> ({1..Q: bytes}, debug dict)"""
+        pts, cols = [], []
+        for f in frames:
+            if "points" not in f:
+                continue
+            pts.append(np.asarray(f["points"]).astype(np.int32))
+            cols.append(np.asarray(f["colors"]).astype(np.float32))
+        n_batch = len(pts)
+        coords = np.concatenate([np.concatenate([np.full((p.shape[0], 1), i, np.int32), p], 1)
+                                 for i, p in enumerate(pts)], 0)
+        feats = np.concatenate([np.ones((coords.shape[0], 1), np.float32), np.concatenate(cols, 0)], 1)
+        keys, feats = self.sparse_tensor(coords, feats)
+        ykeys, y, k = self.g_a(keys, feats, n_batch)
+        ycoords = self.keys_to_coords(ykeys)
+        yperm = self.canonical_perm(ycoords)
+        y_sorted, ycoords_sorted = y[yperm], ycoords[yperm]
+        # geometry: per frame, coords/8 (shared/utils.py:173)
+        yoffs = self.batch_offsets(ykeys, n_batch)
+        points_streams = [self.octree_encode(ycoords[yoffs[f]:yoffs[f + 1], 1:] // 8, 4096)
+                          for f in range(n_batch)]
+        # hyper path
+        zkeys, z = self.h_a(ykeys, y)
+        zcoords = self.keys_to_coords(zkeys)
+        zperm = self.canonical_perm(zcoords)
+        zsym, zhat_sorted = self.factorized_quant(z[zperm])
+        cz = zsym.shape[0]
+        z_string = self.rans_encode(zsym, np.repeat(np.arange(cz, dtype=np.int32), zsym.shape[1]),
+                                    "entropy_bottleneck")
+        zk2, zhat = self.sparse_tensor(zcoords[zperm], zhat_sorted)
+        pkeys, params = self.h_s(zk2, zhat)
+        rows = self.lookup(pkeys, self.morton_keys(ycoords_sorted))
+        prm = np.where(rows[:, None] >= 0, params[np.maximum(rows, 0)], np.float32(0)).astype(np.float32)
+        scale = np.concatenate([self.scale_nn([q]) + self.eps for q in settings], 0).astype(np.float32)
+        sym, idx = self.gaussian_quant(y_sorted, prm, scale)
+        out = {}
+        for qi, q in enumerate(settings):
+            y_string = self.rans_encode(sym[qi], idx[qi], "gaussian_conditional")
+            out[qi + 1] = self.make_bitstream(y_string, z_string, y_sorted.shape[0], zsym.shape[1], points_streams,
+                                              k, q)
+        dbg = {"ykeys": ykeys, "y": y, "k": k, "zkeys": zkeys, "z": z, "params_keys": pkeys, "params": params,
+               "sym": sym, "idx": idx, "zsym": zsym, "points_streams": points_streams, "z_string": z_string,
+               "scale": scale, "num_points": coords.shape[0]}
+        return out, dbg
+
+    @staticmethod
+    def make_bitstream(y_string, z_string, n_y, n_z, points_streams, ks, q):
+        """container writer, codec_pipeline.py:464-517 (big-endian fields)"""
+        parts = [struct.pack(">idd", len(points_streams), float(q[0]), float(q[1])),
+                 struct.pack(">iiii", n_y, n_z, len(y_string), len(z_string)), y_string, z_string]
+        for i, p in enumerate(points_streams):
+            parts.append(struct.pack(">iiii", len(p), int(ks[0][i]), int(ks[1][i]), int(ks[2][i])))
+            parts.append(p)
+        return b"".join(parts)
+
+    @staticmethod
+    def read_bitstream(data):
+        """container reader, codec_parallel.py:173-216"""
+        pos = 0
+        nf, qg, qa = struct.unpack_from(">idd", data, pos); pos += 20
+        n_y, n_z, ly, lz = struct.unpack_from(">iiii", data, pos); pos += 16
+        y_string = data[pos:pos + ly]; pos += ly
+        z_string = data[pos:pos + lz]; pos += lz
+        ks, streams = [[], [], []], []
+        for _ in range(nf):
+            lp, k1, k2, k3 = struct.unpack_from(">iiii", data, pos); pos += 16
+            ks[0].append(k1); ks[1].append(k2); ks[2].append(k3)
+            streams.append(data[pos:pos + lp]); pos += lp
+        return y_string, z_string, n_y, n_z, streams, ks, [qg, qa]
+
+    def decompress(self, data):
+        y_string, z_string, n_y, n_z, streams, ks, q = self.read_bitstream(data)
+        n_batch = len(streams)
+        pts = [self.octree_decode(s) * 8 for s in streams]
+        ycoords = np.concatenate([np.concatenate([np.full((p.shape[0], 1), i, np.int32), p], 1)
+                                  for i, p in enumerate(pts)], 0).astype(np.int32)
+        ykeys = np.sort(self.morton_keys(ycoords))
+        k16, _ = self.down(ykeys, 8)
+        k32, _ = self.down(k16, 16)
+        zcoords = self.keys_to_coords(k32)
+        zcoords_sorted = zcoords[self.canonical_perm(zcoords)]
+        assert zcoords_sorted.shape[0] == n_z
+        cz = self.t["entropy_bottleneck.medians"].shape[0]
+        zsym = self.rans_decode(z_string, np.repeat(np.arange(cz, dtype=np.int32), n_z), "entropy_bottleneck")
+        zhat_sorted = self.factorized_dequant(zsym.reshape(cz, n_z))
+        zk2, zhat = self.sparse_tensor(zcoords_sorted, zhat_sorted)
+        pkeys, params = self.h_s(zk2, zhat)
+        ycoords_sorted = ycoords[self.canonical_perm(ycoords)]
+        assert ycoords_sorted.shape[0] == n_y
+        rows = self.lookup(pkeys, self.morton_keys(ycoords_sorted))
+        prm = np.where(rows[:, None] >= 0, params[np.maximum(rows, 0)], np.float32(0)).astype(np.float32)
+        scale = (self.scale_nn([q]) + self.eps).astype(np.float32)
+        idx = self.gaussian_indexes(prm, scale[0])
+        sym = self.rans_decode(y_string, idx, "gaussian_conditional")
+        yhat_sorted = self.gaussian_dequant(sym.reshape(idx.shape), prm, scale[0])
+        yk2, yhat = self.sparse_tensor(ycoords_sorted, yhat_sorted)
+        xkeys, rgb, offs = self.g_s(yk2, yhat, ks, n_batch)
+        coords = self.keys_to_coords(xkeys)
+        frames = []
+        for f in range(n_batch):
+            c = np.nan_to_num(rgb[offs[f]:offs[f + 1]], nan=0.0)
+            c = np.clip(c * 255.0, 0, 255) / 255
+            frames.append({"points": coords[offs[f]:offs[f + 1], 1:], "colors": c})
+        return frames
