@@ -1,0 +1,300 @@
+"""Op-level parity: libpcc_hip.so (through the C-ABI) vs the CPU oracle on the
+same seeded inputs.  Integer / index work must match bit for bit; float layers
+must match bit for bit too (both sides are the fmaf chain of include/pcc.h)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg, random_cloud, surface_cloud
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(rt, a):
+    return rt.to_device(np.ascontiguousarray(a))
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def u64(t):
+    return host(t).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def clouds():
+    rng = np.random.default_rng(7)
+    return {
+        "rand": random_cloud(rng, 5000, extent=40, batches=3),
+        "surf": surface_cloud(rng, 6000, batches=2),
+        "tiny": random_cloud(rng, 37, extent=6, batches=1),
+        "one": np.array([[0, -5, 7, 9]], dtype=np.int32),
+    }
+
+
+def sorted_keys(oracle, coords):
+    return np.sort(oracle.morton_keys(coords))
+
+
+# ---------------------------------------------------------------- keys / sort
+@pytest.mark.parametrize("name", ["rand", "surf", "tiny", "one"])
+def test_morton_keys_and_inverse(rt, oracle, clouds, name):
+    c = clouds[name]
+    k = rt.morton_keys(dev(rt, c))
+    assert np.array_equal(u64(k), oracle.morton_keys(c))
+    back = rt.keys_to_coords(k)
+    assert np.array_equal(host(back), c)
+
+
+def test_morton_range_error(rt):
+    runtime = pkg("runtime")
+    bad = np.array([[0, 40000, 0, 0]], dtype=np.int32)
+    with pytest.raises(runtime.PccError) as e:
+        rt.morton_keys(dev(rt, bad))
+    assert e.value.code == -3
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1024, 1025, 40000])
+def test_sort_pairs_matches_stable_argsort(rt, n):
+    rng = np.random.default_rng(n)
+    # few distinct values in some digits -> exercises pass skipping and stability
+    keys = (rng.integers(0, 1 << 20, n).astype(np.uint64) << np.uint64(17)) | rng.integers(0, 4, n).astype(np.uint64)
+    k = dev(rt, keys.view(np.int64))
+    perm = rt.sort_pairs(k)
+    ref = np.argsort(keys, kind="stable")
+    assert np.array_equal(host(perm).view(np.uint32), ref.astype(np.uint32))
+    assert np.array_equal(u64(k), keys[ref])
+
+
+def test_sort_pairs_signed(rt):
+    rng = np.random.default_rng(3)
+    keys = rng.integers(-(1 << 62), 1 << 62, 5000, dtype=np.int64)
+    k = dev(rt, keys)
+    perm = rt.sort_pairs(k, signed=True)
+    ref = np.argsort(keys, kind="stable")
+    assert np.array_equal(host(perm).view(np.uint32), ref.astype(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["rand", "surf", "tiny"])
+def test_sort_coords_is_reference_order(rt, oracle, clouds, name):
+    """shared/utils.py:131-133: argsort of b*1e15 + x*1e10 + y*1e5 + z"""
+    c = clouds[name]
+    perm = host(rt.sort_coords(dev(rt, c))).view(np.uint32)
+    assert np.array_equal(perm, oracle.canonical_perm(c).astype(np.uint32))
+    # and it is the lexicographic order for int16-range coordinates
+    srt = c[perm]
+    assert all(tuple(srt[i]) < tuple(srt[i + 1]) for i in range(len(srt) - 1))
+
+
+def test_batch_offsets(rt, oracle, clouds):
+    keys = sorted_keys(oracle, clouds["rand"])
+    offs = rt.batch_offsets(dev(rt, keys.view(np.int64)), 3)
+    assert offs == oracle.batch_offsets(keys, 3)
+
+
+# ---------------------------------------------------------------- coordinate maps
+@pytest.mark.parametrize("name,stride", [("rand", 1), ("surf", 1), ("tiny", 1), ("one", 1), ("surf", 4)])
+def test_down_coords(rt, oracle, clouds, name, stride):
+    c = clouds[name].copy()
+    c[:, 1:] *= stride
+    keys = sorted_keys(oracle, c)
+    pk, nbr8 = rt.down_coords(dev(rt, keys.view(np.int64)), 3 * (stride.bit_length() - 1))
+    rpk, rnbr = oracle.down(keys, stride)
+    assert np.array_equal(u64(pk), rpk)
+    assert np.array_equal(host(nbr8), rnbr)
+
+
+def test_up_coords(rt, oracle, clouds):
+    c = clouds["tiny"].copy()
+    c[:, 1:] *= 8
+    keys = sorted_keys(oracle, c)
+    ck = rt.up_coords(dev(rt, keys.view(np.int64)), 6)
+    assert np.array_equal(u64(ck), oracle.up(keys, 8))
+    assert np.all(np.diff(u64(ck).astype(np.float64)) > 0)  # children come out Morton-sorted
+
+
+@pytest.mark.parametrize("name,stride", [("rand", 1), ("surf", 1), ("tiny", 1), ("one", 1), ("surf", 8)])
+def test_build_map(rt, oracle, clouds, name, stride):
+    c = clouds[name].copy()
+    c[:, 1:] *= stride
+    keys = sorted_keys(oracle, c)
+    nbr = rt.build_map(dev(rt, keys.view(np.int64)), stride)
+    assert np.array_equal(host(nbr), oracle.map27(keys, stride))
+
+
+def test_build_map_edge_of_range(rt, oracle):
+    c = np.array([[0, 32767, 32767, 32767], [0, 32766, 32767, 32767], [0, -32768, -32768, -32768],
+                  [1, -32768, -32768, -32767]], dtype=np.int32)
+    keys = sorted_keys(oracle, c)
+    nbr = rt.build_map(dev(rt, keys.view(np.int64)), 1)
+    assert np.array_equal(host(nbr), oracle.map27(keys, 1))
+
+
+def test_lookup(rt, oracle, clouds):
+    keys = sorted_keys(oracle, clouds["surf"])
+    rng = np.random.default_rng(5)
+    q = np.concatenate([keys[rng.integers(0, len(keys), 500)], oracle.morton_keys(random_cloud(rng, 300, 30, 2))])
+    rows = rt.lookup(dev(rt, keys.view(np.int64)), dev(rt, q.view(np.int64)))
+    assert np.array_equal(host(rows), oracle.lookup(keys, q))
+    feats = rng.normal(size=(len(keys), 8)).astype(np.float32)
+    g = rt.gather_rows_or_zero(dev(rt, feats), rows)
+    ref = np.where(host(rows)[:, None] >= 0, feats[np.maximum(host(rows), 0)], 0).astype(np.float32)
+    assert np.array_equal(host(g), ref)
+
+
+# ---------------------------------------------------------------- layers
+def _weights(rng, k, cin, cout):
+    return (rng.normal(0, 0.3, (k, cin, cout)).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32))
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (3, 5), (32, 1)])
+@pytest.mark.parametrize("name", ["surf", "tiny", "one"])
+@pytest.mark.parametrize("relu", [False, True])
+def test_sparse_conv3_bit_exact(rt, oracle, clouds, cin, cout, name, relu):
+    rng = np.random.default_rng(cin * 100 + cout)
+    keys = sorted_keys(oracle, clouds[name])
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(len(keys), cin)).astype(np.float32)
+    w, b = _weights(rng, 27, cin, cout)
+    out = rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), relu)
+    ref = oracle.sparse_conv(x, nbr, w, b, relu)
+    assert np.array_equal(host(out), ref)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (4, 32)])
+def test_sparse_conv_down_bit_exact(rt, oracle, clouds, cin, cout):
+    rng = np.random.default_rng(11)
+    keys = sorted_keys(oracle, clouds["surf"])
+    pk, nbr8 = oracle.down(keys, 1)
+    x = rng.normal(size=(len(keys), cin)).astype(np.float32)
+    w, b = _weights(rng, 8, cin, cout)
+    out = rt.sparse_conv(dev(rt, x), dev(rt, nbr8), dev(rt, w), dev(rt, b), True)
+    assert np.array_equal(host(out), oracle.sparse_conv(x, nbr8, w, b, True))
+
+
+def test_conv_linearity(rt, oracle, clouds):
+    """size-independent property: conv(a*x) == a*conv(x) for a power of two, zero bias"""
+    rng = np.random.default_rng(12)
+    keys = sorted_keys(oracle, clouds["surf"])
+    nbr = dev(rt, oracle.map27(keys, 1))
+    x = rng.normal(size=(len(keys), 32)).astype(np.float32)
+    w, _ = _weights(rng, 27, 32, 32)
+    b = np.zeros(32, np.float32)
+    o1 = host(rt.sparse_conv(dev(rt, x), nbr, dev(rt, w), dev(rt, b), False))
+    o2 = host(rt.sparse_conv(dev(rt, x * 4), nbr, dev(rt, w), dev(rt, b), False))
+    assert np.array_equal(o1 * 4, o2)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (5, 3)])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 700])
+def test_convT_gen_bit_exact(rt, oracle, cin, cout, n):
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    w, b = _weights(rng, 8, cin, cout)
+    out = rt.convT_gen(dev(rt, x), dev(rt, w), dev(rt, b), True)
+    assert np.array_equal(host(out), oracle.convT(x, w, b, True))
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 1), (32, 3), (7, 9)])
+def test_linear_bit_exact(rt, oracle, cin, cout):
+    rng = np.random.default_rng(cin)
+    x = rng.normal(size=(1000, cin)).astype(np.float32)
+    w = rng.normal(0, 0.3, (cin, cout)).astype(np.float32)
+    b = rng.normal(0, 0.1, cout).astype(np.float32)
+    out = rt.linear(dev(rt, x), dev(rt, w), dev(rt, b), False)
+    assert np.array_equal(host(out), oracle.linear(x, w, b))
+
+
+# ---------------------------------------------------------------- top-k
+@pytest.mark.parametrize("case", ["random", "ties", "all_equal", "k_zero_and_all", "negatives"])
+def test_topk_prune(rt, oracle, case):
+    rng = np.random.default_rng({"random": 1, "ties": 2, "all_equal": 3, "k_zero_and_all": 4, "negatives": 5}[case])
+    counts = [3000, 1, 0, 5000]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    n = offs[-1]
+    if case == "random":
+        lg = rng.normal(size=n).astype(np.float32)
+        k = [1000, 1, 0, 2500]
+    elif case == "ties":
+        lg = rng.integers(-3, 3, n).astype(np.float32)  # heavy ties at the threshold
+        k = [1234, 1, 0, 4999]
+    elif case == "all_equal":
+        lg = np.full(n, 0.25, np.float32)
+        k = [17, 1, 0, 100]
+    elif case == "k_zero_and_all":
+        lg = rng.normal(size=n).astype(np.float32)
+        k = [0, 5, 0, 5000]
+    else:
+        lg = -np.abs(rng.normal(size=n)).astype(np.float32)
+        lg[::7] = 0.0
+        lg[::13] = -0.0
+        k = [500, 0, 0, 700]
+    kc = [min(a, b) for a, b in zip(k, counts)]
+    keep = rt.topk_prune(dev(rt, lg), offs, kc)
+    ref = oracle.topk(lg, offs, kc)
+    assert np.array_equal(host(keep).view(np.uint32), ref)
+
+
+# ---------------------------------------------------------------- entropy kernels
+def test_factorized_quant_dequant(rt, oracle):
+    rng = np.random.default_rng(21)
+    z = (rng.normal(size=(777, 32)) * 3).astype(np.float32)
+    z[0, :] = np.float32(0.5) + oracle.t["entropy_bottleneck.medians"]  # exact ties -> round half even
+    med = dev(rt, oracle.t["entropy_bottleneck.medians"])
+    sym, zhat = rt.factorized_quant(dev(rt, z), med)
+    rs, rz = oracle.factorized_quant(z)
+    assert np.array_equal(host(sym), rs) and np.array_equal(host(zhat), rz)
+    assert np.array_equal(host(rt.factorized_dequant(sym, med)), oracle.factorized_dequant(rs))
+
+
+def test_gaussian_quant_indexes_dequant(rt, oracle):
+    rng = np.random.default_rng(22)
+    n, c = 1501, 32
+    y = (rng.normal(size=(n, c)) * 2).astype(np.float32)
+    params = np.concatenate([np.abs(rng.normal(1.5, 3.0, (n, c))), rng.normal(0, 1, (n, c))], 1).astype(np.float32)
+    params[:5, :c] = -1.0      # below the lower bound
+    params[5:10, :c] = 1000.0  # above the table
+    scale = (oracle.scale_nn([[1, 0], [0, 1], [1, 1]]) + oracle.eps).astype(np.float32)
+    tab = dev(rt, oracle.t["gaussian_conditional.scale_table"])
+    sym, idx = rt.gaussian_quant(dev(rt, y), dev(rt, params), dev(rt, scale), tab)
+    rs, ri = oracle.gaussian_quant(y, params, scale)
+    assert np.array_equal(host(sym), rs) and np.array_equal(host(idx), ri)
+    i1 = rt.gaussian_indexes(dev(rt, params), dev(rt, scale[2]), tab)
+    assert np.array_equal(host(i1), oracle.gaussian_indexes(params, scale[2]))
+    assert np.array_equal(host(i1), ri[2])
+    yh = rt.gaussian_dequant(dev(rt, rs[2]), dev(rt, params), dev(rt, scale[2]), float(oracle.t[
+        "gaussian_conditional.scale_table"][0]), float(oracle.off_a), float(oracle.off_b))
+    assert np.array_equal(host(yh), oracle.gaussian_dequant(rs[2], params, scale[2]))
+
+
+# ---------------------------------------------------------------- octree
+@pytest.mark.parametrize("name", ["surf", "tiny", "one", "rand"])
+def test_octree_blob_matches_oracle_and_round_trips(rt, oracle, clouds, name):
+    runtime, utils = pkg("runtime"), pkg("utils")
+    c = clouds[name].copy()
+    c = c[c[:, 0] == 0]
+    c[:, 1:] *= 8
+    keys = sorted_keys(oracle, c)
+    kd = dev(rt, keys.view(np.int64))
+    blob = utils.gpcc_encode(kd, keys.view(np.int64), 0, len(keys), 9)
+    ref = oracle.octree_encode(c[:, 1:] // 8, 4096)
+    assert blob == ref
+    pts = utils.gpcc_decode(blob, 8)
+    assert np.array_equal(pts, oracle.keys_to_coords(keys)[:, 1:])
+    assert np.array_equal(oracle.octree_decode(blob) * 8, pts)
+
+
+def test_octree_stride1_large_extent(rt, oracle):
+    """geometry-only use (KITTI-like): stride-1 keys, coordinates spanning +-2000"""
+    runtime, utils = pkg("runtime"), pkg("utils")
+    rng = np.random.default_rng(9)
+    c = random_cloud(rng, 3000, extent=4000, batches=1, lo=-2000)
+    keys = sorted_keys(oracle, c)
+    blob = utils.gpcc_encode(dev(rt, keys.view(np.int64)), keys.view(np.int64), 0, len(keys), 0)
+    assert blob == oracle.octree_encode(c[:, 1:], 32768)
+    assert np.array_equal(utils.gpcc_decode(blob, 1), oracle.keys_to_coords(keys)[:, 1:])
