@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of encode+decode on the ScanNet-scale 1M-point frame.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver under torch.distributed.run, one rank per GPU)
+
+One step = CompressionPipeline.compress(gop of one 1M-point frame, the three
+quality settings of shared/config.yaml:12-15) + DecompressionPipeline.
+decompress(container of the last quality).  Inputs are resident in HBM when the
+timed region starts and the decoded frame stays in HBM (DESIGN.md notes the
+PCIe-inclusive rate).  N > 1: every rank codes its own frame (the path shards by
+frame / tile, no data-path collective), value = frames of all ranks / max time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "demo-learned-point-cloud-compression_amd"
+
+SETTINGS = [[1.0, 0.0], [0.0, 1.0], [1, 1]]      # /root/reference/shared/config.yaml:12-15
+HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def conv_algorithmic(n_out, n_in, cin, cout, k_vol, pairs):
+    """bytes = 4(N_in Cin + N_out Cout) + 4 K Cin Cout + 4 P + 4 (N_out+1); flops = 2 P Cin Cout"""
+    nbytes = 4 * (n_in * cin + n_out * cout) + 4 * k_vol * cin * cout + 4 * pairs + 4 * (n_out + 1)
+    return nbytes, 2 * pairs * cin * cout
+
+
+def cpu_baseline(wl, frame, n_sample, threads):
+    """CPU restatement (oracle) on a bounded spatial crop of the same frame"""
+    from oracle.codec_ref import Oracle
+    pts = frame["points"].astype(np.int64)
+    # spatial crop: the n_sample points nearest (in Chebyshev distance) to the centroid keep the surface statistics
+    c = np.median(pts, axis=0)
+    d = np.abs(pts - c).max(axis=1)
+    keep = np.argsort(d, kind="stable")[:n_sample]
+    sample = {"points": frame["points"][keep], "colors": frame["colors"][keep]}
+    o = Oracle(threads=threads)
+    t0 = time.time()
+    out, dbg = o.compress([sample], SETTINGS)
+    t1 = time.time()
+    o.decompress(out[len(SETTINGS)])
+    t2 = time.time()
+    n = sample["points"].shape[0]
+    return {"value": (n / 1.0e6) / (t2 - t0), "unit": "frames/s (1M-point equivalent, linear in points)",
+            "cores": threads, "kind": "port",
+            "sample": f"{n}-point spatial crop of the same frame, Q=3 encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s, "
+                      f"oracle/ C restatement with OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=60_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pkg = importlib.import_module(PKG)
+    wl = importlib.import_module(PKG + ".workloads")
+
+    t0 = time.time()
+    frame = wl.room(args.points, seed=rank)
+    n_pts = int(frame["points"].shape[0])
+    log(f"[rank {rank}] workload: {n_pts} voxels generated in {time.time() - t0:.1f}s")
+    dev = torch.device("cuda", local)
+    d_points = torch.from_numpy(frame["points"].astype(np.int32)).to(dev)
+    d_colors = torch.from_numpy(frame["colors"].astype(np.float32)).to(dev)
+
+    enc = pkg.CompressionPipeline(SETTINGS, device=local, slots=1)
+    dec = pkg.DecompressionPipeline(device=local, slots=1, output="device")
+    q_dec = len(SETTINGS)
+
+    def step():
+        gop = {"frames": [{"points": d_points, "colors": d_colors}], "timestamps": {}}
+        out, side = enc.compress(gop)
+        rec, dside = dec.decompress(out[q_dec])
+        return out, side, rec, dside
+
+    for _ in range(args.warmup):
+        out, side, rec, dside = step()
+    assert rec[0]["points"].shape[0] == n_pts
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for r in enc.runtimes + dec.runtimes:
+        r.prof_enable(True)
+    fence()
+    t_start = time.perf_counter()
+    enc_ms, dec_ms = [], []
+    for _ in range(args.steps):
+        out, side, rec, dside = step()
+        enc_ms.append(1e3 * (side["timestamps"]["codec_end"] - side["timestamps"]["codec_start"]))
+        dec_ms.append(1e3 * (dside["timestamps"]["codec_end"] - dside["timestamps"]["codec_start"]))
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-launch records of the timed region (HIP events on the ctx streams)
+    recs = []
+    for r in enc.runtimes + dec.runtimes:
+        recs += r.prof_records()
+        r.prof_enable(False)
+    groups = {}
+    for op, ms, dims in recs:
+        g = groups.setdefault((op, dims), [0, 0.0])
+        g[0] += 1
+        g[1] += ms
+    table = sorted(groups.items(), key=lambda kv: -kv[1][1])
+    if rank == 0:
+        log("per-op device time over the timed region (HIP events):")
+        for (op, dims), (cnt, tot) in table[:25]:
+            log(f"  {op:14s} {str(dims):34s} x{cnt:4d}  total {tot:9.3f} ms  avg {tot / cnt:8.4f} ms")
+        log(f"  sum of recorded ops per step: {sum(v[1] for v in groups.values()) / args.steps:.3f} ms; "
+            f"wall per step {1e3 * elapsed / args.steps:.3f} ms (enc {np.mean(enc_ms):.2f} + dec {np.mean(dec_ms):.2f})")
+        st = side["enc_time_measurements"]
+        log("  encode stages ms:", {k: (round(1e3 * v, 3) if not isinstance(v, list) else [round(1e3 * x, 3) for x in v])
+                                    for k, v in st.items()})
+        log("  decode stages ms:", {k: round(1e3 * v, 3) for k, v in dside["time_measurements"].items()})
+
+    # ---- roofline of the dominant kernel (largest total device time among the layer kernels)
+    roofline = None
+    layer_ops = [(k, v) for k, v in table if k[0] in ("sparse_conv", "convT_gen")]
+    if layer_ops and rank == 0:
+        (op, dims), (cnt, tot) = layer_ops[0]
+        avg_s = tot / cnt / 1e3
+        # one extra untimed step to count the active pairs of every rule book
+        for r in enc.runtimes + dec.runtimes:
+            r.pairs_log = {}
+        step()
+        pairs = {}
+        for r in enc.runtimes + dec.runtimes:
+            pairs.update(r.pairs_log)
+            r.pairs_log = None
+        n_out, cin, cout, k_vol = dims
+        if op == "sparse_conv" and k_vol == 27:
+            p = pairs.get(n_out, 0)
+            nbytes, flops = conv_algorithmic(n_out, n_out, cin, cout, 27, p)
+        elif op == "sparse_conv":
+            # stride-2 kernel-2: every input row feeds exactly one output row
+            p = max(pairs.values()) if pairs else n_out
+            nbytes, flops = conv_algorithmic(n_out, p, cin, cout, k_vol, p)
+        else:
+            p = n_out * 8
+            nbytes = 4 * (n_out * cin + 8 * n_out * cout) + 4 * 8 * cin * cout
+            flops = 2 * p * cin * cout
+        t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        if t_mfma >= t_hbm:
+            ach = flops / avg_s / 1e12
+            roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None}
+        else:
+            ach = nbytes / avg_s / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        roofline.update({"kernel": f"{op}{list(dims)}", "avg_ms": avg_s * 1e3, "launches": cnt,
+                         "algorithmic_bytes": nbytes, "algorithmic_flops": flops, "active_pairs": p})
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(wl, frame, args.cpu_sample, os.cpu_count() or 1)
+        except Exception as e:      # the oracle is only a reported baseline; never fail the bench on it
+            log("cpu_baseline failed:", repr(e))
+
+    if rank == 0:
+        frames_total = args.steps * world
+        line = {
+            "metric": "point-cloud frames/sec encode+decode @1M pts",
+            "value": frames_total / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2 ScanNet-scale 1M-point frame (BASELINE.json configs[1]): seeded indoor scene, "
+                                   "512x512x256 grid, F=1 frame per GOP, Q=3 settings, hyperprior model demo_small "
+                                   "(seeded synthetic weights)",
+                       "points_per_frame": n_pts, "frames_per_step_per_gpu": 1, "qualities": len(SETTINGS),
+                       "decoded_quality": q_dec, "sharding": "one frame per GPU, no data-path collective"},
+            "encode_ms": float(np.mean(enc_ms)), "decode_ms": float(np.mean(dec_ms)),
+            "bpp": [float(b) for b in side["gop_info"]["bpp"]],
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

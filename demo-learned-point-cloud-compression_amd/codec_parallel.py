@@ -25,8 +25,9 @@ class DecompressionPipeline:
         self.decompression_model = self.load_model(base_path)
         self.output = output                  # "numpy" (reference behaviour) or "device"
         self._slots = queue.Queue()
-        for _ in range(slots):
-            self._slots.put(_rt.Runtime(device))
+        self.runtimes = [_rt.Runtime(device) for _ in range(slots)]
+        for r in self.runtimes:
+            self._slots.put(r)
 
     def load_model(self, base_path):
         model_name = "demo_small"

@@ -33,8 +33,9 @@ class CompressionPipeline:
         base_path = "./unified/results/"          # kept for signature parity; the checkpoint ships in-tree
         self.compression_model = self.load_model(base_path)
         self._slots = queue.Queue()
-        for _ in range(slots):
-            self._slots.put(_rt.Runtime(device))
+        self.runtimes = [_rt.Runtime(device) for _ in range(slots)]
+        for r in self.runtimes:
+            self._slots.put(r)
         em = self.compression_model.entropy_model
         # scale_nn(q)+eps for every quality, once (it depends on settings only)
         scale = np.concatenate([em.scale_nn(np.asarray([q], dtype=np.float32)) + em.eps for q in self.settings], 0)

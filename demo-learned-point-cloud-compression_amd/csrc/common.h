@@ -48,6 +48,25 @@ struct pcc_ctx {
   size_t pinned_cap;
   hipEvent_t ev0, ev1;
   bool ev_valid;
+  // per-launch profiler (bench.py roofline figure): event pairs around the
+  // kernels of an API call, read back after a synchronise
+  bool prof_on;
+  int prof_n, prof_cap;
+  struct pcc_prof_rec* prof;
+};
+
+struct pcc_prof_rec {
+  hipEvent_t e0, e1;
+  const char* op;
+  int64_t dims[4];
+};
+
+// RAII event pair around the launches of one C-ABI call (no-op unless enabled)
+struct PccProfScope {
+  pcc_ctx* c;
+  int slot;
+  PccProfScope(pcc_ctx* ctx, const char* op, int64_t d0, int64_t d1, int64_t d2, int64_t d3);
+  ~PccProfScope();
 };
 
 // Reset the arena at the start of an API call.

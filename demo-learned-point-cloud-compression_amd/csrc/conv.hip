@@ -251,6 +251,7 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
               "pcc_sparse_conv: bad buffers (pitch %lld, n_out %lld, n_in %lld)", (long long)nbr_pitch,
               (long long)n_out, (long long)n_in);
   hipStream_t st = ctx->stream;
+  PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
   const unsigned gm = nblk(n_out, 32 * GC_WAVES);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
   if (!force_scalar() && aligned && cin == 32 && cout == 32) {
@@ -278,6 +279,7 @@ extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, cons
   if (n_in <= 0) return PCC_OK;
   PCC_REQUIRE(d_in && d_w && d_bias && d_out, PCC_E_ARG, "pcc_convT_gen: null buffers");
   hipStream_t st = ctx->stream;
+  PccProfScope prof(ctx, "convT_gen", n_in, cin, cout, 8);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
   if (!force_scalar() && aligned && cin == 32 && cout == 32) {
     hipLaunchKernelGGL((k_convT_mfma<1>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
@@ -300,6 +302,7 @@ extern "C" int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const floa
               "pcc_linear: cin=%d cout=%d unsupported", cin, cout);
   if (n <= 0) return PCC_OK;
   PCC_REQUIRE(d_in && d_w && d_bias && d_out, PCC_E_ARG, "pcc_linear: null buffers");
+  PccProfScope prof(ctx, "linear", n, cin, cout, 1);
   hipLaunchKernelGGL(k_linear, dim3(nblk(n * cout, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
                      d_bias, cin, cout, relu, d_out);
   PCC_CHECK_LAUNCH();

@@ -53,6 +53,9 @@ extern "C" void pcc_destroy(pcc_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  for (int i = 0; i < c->prof_cap; ++i)
+    if (c->prof[i].e0) { (void)hipEventDestroy(c->prof[i].e0); (void)hipEventDestroy(c->prof[i].e1); }
+  free(c->prof);
   free(c);
 }
 
@@ -113,4 +116,79 @@ void* pcc_arena_alloc(pcc_ctx* c, size_t bytes) {
   }
   c->arena_off = off + bytes;
   return c->arena + off;
+}
+
+// ---------------------------------------------------------------- profiler
+PccProfScope::PccProfScope(pcc_ctx* ctx, const char* op, int64_t d0, int64_t d1, int64_t d2, int64_t d3)
+    : c(ctx), slot(-1) {
+  if (!c || !c->prof_on) return;
+  if (c->prof_n == c->prof_cap) {
+    const int ncap = c->prof_cap ? c->prof_cap * 2 : 256;
+    pcc_prof_rec* np = (pcc_prof_rec*)realloc(c->prof, sizeof(pcc_prof_rec) * (size_t)ncap);
+    if (!np) return;
+    for (int i = c->prof_cap; i < ncap; ++i) {
+      np[i].e0 = nullptr;
+      np[i].e1 = nullptr;
+    }
+    c->prof = np;
+    c->prof_cap = ncap;
+  }
+  pcc_prof_rec& r = c->prof[c->prof_n];
+  if (!r.e0 && (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess)) return;
+  r.op = op;
+  r.dims[0] = d0; r.dims[1] = d1; r.dims[2] = d2; r.dims[3] = d3;
+  if (hipEventRecord(r.e0, c->stream) != hipSuccess) return;
+  slot = c->prof_n++;
+}
+
+PccProfScope::~PccProfScope() {
+  if (slot >= 0) (void)hipEventRecord(c->prof[slot].e1, c->stream);
+}
+
+extern "C" int pcc_prof_enable(pcc_ctx* c, int on) {
+  PCC_REQUIRE(c, PCC_E_ARG, "null ctx");
+  c->prof_on = on != 0;
+  c->prof_n = 0;
+  return PCC_OK;
+}
+
+extern "C" int pcc_prof_count(pcc_ctx* c) { return c ? c->prof_n : 0; }
+
+extern "C" int pcc_prof_get(pcc_ctx* c, int i, char* h_op, int cap, float* h_ms, int64_t* h_dims) {
+  PCC_REQUIRE(c && h_op && h_ms && h_dims && cap > 0, PCC_E_ARG, "pcc_prof_get: null arg");
+  PCC_REQUIRE(i >= 0 && i < c->prof_n, PCC_E_ARG, "pcc_prof_get: index %d of %d", i, c->prof_n);
+  pcc_prof_rec& r = c->prof[i];
+  PCC_HIP(hipEventSynchronize(r.e1));
+  PCC_HIP(hipEventElapsedTime(h_ms, r.e0, r.e1));
+  snprintf(h_op, (size_t)cap, "%s", r.op);
+  for (int k = 0; k < 4; ++k) h_dims[k] = r.dims[k];
+  return PCC_OK;
+}
+
+// number of entries >= 0 in an int32 array (active pairs of a rule book)
+__global__ void k_count_nonneg(const int32_t* __restrict__ p, int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    c += p[i] >= 0 ? 1ull : 0ull;
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+extern "C" int pcc_count_nonneg(pcc_ctx* c, const int32_t* d_p, int64_t n, int64_t* h_count) {
+  PCC_REQUIRE(c && h_count, PCC_E_ARG, "pcc_count_nonneg: null arg");
+  *h_count = 0;
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_p, PCC_E_ARG, "pcc_count_nonneg: null buffer");
+  PCC_TRY(pcc_arena_reserve(c, 256));
+  unsigned long long* out = (unsigned long long*)pcc_arena_alloc(c, 8);
+  if (!out) return PCC_E_NOMEM;
+  PCC_HIP(hipMemsetAsync(out, 0, 8, c->stream));
+  unsigned g = (unsigned)((n + 255) / 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_count_nonneg, dim3(g), dim3(256), 0, c->stream, d_p, n, out);
+  PCC_CHECK_LAUNCH();
+  PCC_HIP(hipMemcpyAsync(c->pinned, out, 8, hipMemcpyDeviceToHost, c->stream));
+  PCC_HIP(hipStreamSynchronize(c->stream));
+  *h_count = (int64_t)*(unsigned long long*)c->pinned;
+  return PCC_OK;
 }

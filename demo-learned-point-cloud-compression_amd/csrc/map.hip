@@ -142,6 +142,7 @@ extern "C" int pcc_build_map(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, in
   unsigned long long* tk;
   uint32_t* tv;
   uint64_t mask;
+  PccProfScope prof(ctx, "build_map", n, stride, 0, 27);
   PCC_TRY(build_table(ctx, d_keys, n, &tk, &tv, &mask));
   hipLaunchKernelGGL(k_build_map27, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_keys, n,
                      stride, (const unsigned long long*)tk, (const uint32_t*)tv, mask, d_nbr);
@@ -160,6 +161,7 @@ extern "C" int pcc_lookup(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, const
   unsigned long long* tk;
   uint32_t* tv;
   uint64_t mask;
+  PccProfScope prof(ctx, "lookup", n, m, 0, 0);
   PCC_TRY(build_table(ctx, d_keys, n, &tk, &tv, &mask));
   hipLaunchKernelGGL(k_lookup, dim3(nblk(m, 256)), dim3(256), 0, ctx->stream, d_qkeys, m,
                      (const unsigned long long*)tk, (const uint32_t*)tv, mask, d_rows);

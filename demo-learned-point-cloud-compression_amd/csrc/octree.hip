@@ -67,6 +67,7 @@ extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n
   uint32_t* counts = (uint32_t*)pcc_arena_alloc(ctx, (size_t)(depth + 1) * 4);  // counts[L] = nodes at level L
   if (!buf_a || !buf_b || !flags || !excl || !occ_lv || !counts) return PCC_E_NOMEM;
   const size_t mark = ctx->arena_off;
+  PccProfScope prof(ctx, "octree_levels", n, depth, 0, 0);
 
   hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + depth, (uint32_t)n);
   PCC_CHECK_LAUNCH();

@@ -61,6 +61,7 @@ extern "C" int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, 
   uint32_t* excl = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
   uint32_t* total = (uint32_t*)pcc_arena_alloc(ctx, 4);
   if (!flags || !excl || !total) return PCC_E_NOMEM;
+  PccProfScope prof(ctx, "down_coords", n, child_shift, 0, 0);
   hipLaunchKernelGGL(k_parent_flags, dim3(nblk(n, 256)), dim3(256), 0, st, d_keys, n,
                      child_shift + 3, flags);
   PCC_CHECK_LAUNCH();

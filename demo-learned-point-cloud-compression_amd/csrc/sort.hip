@@ -302,6 +302,7 @@ extern "C" int pcc_sort_pairs(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, 
   PCC_REQUIRE(ctx && (n == 0 || (d_keys && d_perm)), PCC_E_ARG, "pcc_sort_pairs: null arg");
   PCC_REQUIRE(n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_sort_pairs: n too large");
   PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n)));
+  PccProfScope prof(ctx, "sort_pairs", n, is_signed, 0, 0);
   return sort_pairs_impl(ctx, d_keys, d_perm, n, is_signed);
 }
 
@@ -313,6 +314,7 @@ extern "C" int pcc_sort_coords(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
   PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n) + pcc_align((size_t)n * 8)));
   int64_t* lk = (int64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
   if (!lk) return PCC_E_NOMEM;
+  PccProfScope prof(ctx, "sort_coords", n, 0, 0, 0);
   hipLaunchKernelGGL(k_linear_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
                      (const int4*)d_coords, n, lk);
   PCC_CHECK_LAUNCH();
@@ -324,6 +326,7 @@ extern "C" int pcc_gather_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* 
   PCC_REQUIRE(ctx && (n == 0 || (d_src && d_perm && d_dst)), PCC_E_ARG, "pcc_gather_rows: null arg");
   PCC_REQUIRE(row_bytes > 0 && row_bytes % 4 == 0, PCC_E_ARG, "pcc_gather_rows: row_bytes %d", row_bytes);
   if (n <= 0) return PCC_OK;
+  PccProfScope prof(ctx, "gather_rows", n, row_bytes, 0, 0);
   if (row_bytes % 16 == 0 && ((uintptr_t)d_src % 16 == 0) && ((uintptr_t)d_dst % 16 == 0)) {
     int vec = row_bytes / 16;
     hipLaunchKernelGGL(k_gather_rows16, dim3(nblk(n * vec, 256)), dim3(256), 0, ctx->stream,

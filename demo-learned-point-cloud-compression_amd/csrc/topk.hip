@@ -139,6 +139,7 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
   uint32_t* total = (uint32_t*)pcc_arena_alloc(ctx, 4);
   if (!keys || !fl || !ex || !hist || !offs || !state || !total) return PCC_E_NOMEM;
   const size_t mark = ctx->arena_off;
+  PccProfScope prof(ctx, "topk_prune", n, n_batch, 0, 0);
 
   // stage per-frame parameters through the pinned buffer
   char* hp = (char*)ctx->pinned;

@@ -101,6 +101,26 @@ class Runtime:
         check(self.lib.pcc_timer_elapsed_ms(self.ctx, C.byref(ms)), "pcc_timer_elapsed_ms")
         return ms.value
 
+    # ------------------------------------------------------------ per-launch profiler
+    def prof_enable(self, on=True):
+        check(self.lib.pcc_prof_enable(self.ctx, 1 if on else 0), "pcc_prof_enable")
+
+    def prof_records(self):
+        """[(op, ms, (d0,d1,d2,d3)), ...] of every C-ABI call since prof_enable (synchronises)"""
+        out = []
+        name = C.create_string_buffer(64)
+        ms = C.c_float(0)
+        dims = (C.c_int64 * 4)()
+        for i in range(self.lib.pcc_prof_count(self.ctx)):
+            check(self.lib.pcc_prof_get(self.ctx, i, name, 64, C.byref(ms), dims), "pcc_prof_get")
+            out.append((name.value.decode(), float(ms.value), tuple(int(d) for d in dims)))
+        return out
+
+    def count_nonneg(self, t):
+        cnt = C.c_int64(0)
+        check(self.lib.pcc_count_nonneg(self.ctx, _ptr(t), t.numel(), C.byref(cnt)), "pcc_count_nonneg")
+        return cnt.value
+
     # ------------------------------------------------------------ keys / order
     def morton_keys(self, coords):
         n = coords.shape[0]

@@ -61,6 +61,9 @@ class CoordSet:
     def nbr27(self):
         if self._nbr27 is None:
             self._nbr27 = self.rt.build_map(self.keys, self.stride)
+            log = getattr(self.rt, "pairs_log", None)
+            if log is not None:     # bench.py: active-pair count of each rule book, keyed by row count
+                log[self.n] = self.rt.count_nonneg(self._nbr27)
         return self._nbr27
 
     def down(self):

@@ -80,6 +80,19 @@ int pcc_timer_start(pcc_ctx* ctx);
 int pcc_timer_stop(pcc_ctx* ctx);
 int pcc_timer_elapsed_ms(pcc_ctx* ctx, float* h_ms);
 
+/* per-launch profiler: when enabled, every device entry point below brackets
+ * its launches with a hipEvent pair on the ctx stream.  pcc_prof_get returns
+ * the op name, its elapsed ms and four shape numbers (op-specific; for
+ * sparse_conv: n_out, cin, cout, k_vol).  Used by bench.py for the roofline
+ * figure of the dominant kernel. */
+int pcc_prof_enable(pcc_ctx* ctx, int on);
+int pcc_prof_count(pcc_ctx* ctx);
+int pcc_prof_get(pcc_ctx* ctx, int i, char* h_op, int cap, float* h_ms,
+                 int64_t* h_dims);
+/* number of entries >= 0 (active pairs of a rule book) */
+int pcc_count_nonneg(pcc_ctx* ctx, const int32_t* d_p, int64_t n,
+                     int64_t* h_count);
+
 /* ---- coordinate keys and ordering ------------------------------------- */
 
 /* replaces: MinkowskiEngine coordinate-map insertion inside every
