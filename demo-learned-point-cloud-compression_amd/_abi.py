@@ -47,7 +47,10 @@ PROTOTYPES = {
     "pcc_gather_rows": (i32, [vp, vp, vp, i64, i32, vp]),
     "pcc_check_unique": (i32, [vp, vp, i64, pi32]),
     "pcc_batch_offsets": (i32, [vp, vp, i64, i32, pi64]),
-    "pcc_down_coords": (i32, [vp, vp, i64, i32, vp, vp, i64, pi64]),
+    "pcc_down_coords": (i32, [vp, vp, i64, i32, vp, vp, i64, vp, pi64]),
+    "pcc_derive_map_up": (i32, [vp, vp, i64, vp, vp, i64, vp]),
+    "pcc_derive_map_down": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp]),
+    "pcc_inverse_rows": (i32, [vp, vp, i64, i64, vp]),
     "pcc_up_coords": (i32, [vp, vp, i64, i32, vp]),
     "pcc_build_map": (i32, [vp, vp, i64, i32, vp]),
     "pcc_lookup": (i32, [vp, vp, i64, vp, i64, vp]),
@@ -60,6 +63,10 @@ PROTOTYPES = {
     "pcc_factorized_dequant": (i32, [vp, vp, i64, i32, vp, vp]),
     "pcc_gaussian_quant": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "pcc_gaussian_indexes": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
+    "pcc_gaussian_quant16": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, vp]),
+    "pcc_gaussian_indexes8": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
+    "pcc_rans_encode_multi16": (i32, [vp, vp, i64, i32, vp, i32, vp, vp, i32, vp, i64, pi64]),
+    "pcc_rans_decode8": (i32, [vp, i64, vp, i64, vp, i32, vp, vp, i32, vp]),
     "pcc_gaussian_dequant": (i32, [vp, vp, vp, i64, i32, vp, f32, f32, f32, vp]),
     "pcc_rans_encode": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i64, pi64]),
     "pcc_rans_decode": (i32, [vp, i64, vp, i64, vp, i32, vp, vp, i32, vp]),
@@ -69,6 +76,34 @@ PROTOTYPES = {
     "pcc_octree_peek": (i32, [vp, i64, pi64, pi32, pi32]),
     "pcc_octree_unpack": (i32, [vp, i64, vp, i64]),
 }
+
+def host_cpu_budget():
+    """CPUs this process may actually use: min(visible cores, cgroup quota).  On the GPU boxes
+    256 cores are visible but the cgroup grants 16; thread pools sized by os.cpu_count()
+    (torch intra-op, OpenMP) then spin 256 threads, exhaust the quota and the whole process is
+    throttled for tens of ms at a time."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, quota // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
 
 _lib = None
 

@@ -147,8 +147,25 @@ PccProfScope::~PccProfScope() {
 
 extern "C" int pcc_prof_enable(pcc_ctx* c, int on) {
   PCC_REQUIRE(c, PCC_E_ARG, "null ctx");
-  c->prof_on = on != 0;
   c->prof_n = 0;
+  // `on` > 1 pre-creates that many event pairs so that the timed region only records
+  if (on > 1 && on > c->prof_cap) {
+    pcc_prof_rec* np = (pcc_prof_rec*)realloc(c->prof, sizeof(pcc_prof_rec) * (size_t)on);
+    PCC_REQUIRE(np, PCC_E_NOMEM, "pcc_prof_enable: out of memory");
+    for (int i = c->prof_cap; i < on; ++i) {
+      np[i].e0 = nullptr;
+      np[i].e1 = nullptr;
+    }
+    c->prof = np;
+    c->prof_cap = on;
+  }
+  if (on > 1)
+    for (int i = 0; i < c->prof_cap; ++i)
+      if (!c->prof[i].e0) {
+        PCC_HIP(hipEventCreate(&c->prof[i].e0));
+        PCC_HIP(hipEventCreate(&c->prof[i].e1));
+      }
+  c->prof_on = on != 0;
   return PCC_OK;
 }
 

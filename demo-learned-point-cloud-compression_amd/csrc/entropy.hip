@@ -70,6 +70,47 @@ __global__ __launch_bounds__(256) void k_gaussian_quant(
   }
 }
 
+// compact form: int16 symbols / uint8 indexes (3 B instead of 8 B per symbol over PCIe);
+// *flag is OR-ed with 1 if a symbol does not fit int16 (caller then uses the int32 form)
+__global__ __launch_bounds__(256) void k_gaussian_quant16(
+    const float* __restrict__ y, const float* __restrict__ params, int64_t n, int c,
+    const float* __restrict__ scale, int nq, const float* __restrict__ table, int n_tab,
+    int16_t* __restrict__ sym, uint8_t* __restrict__ idx, int32_t* __restrict__ flag) {
+  __shared__ float tab[64];
+  if (threadIdx.x < n_tab) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  const int ch = (int)(t / n);
+  const int64_t i = t - (int64_t)ch * n;
+  const float yv = y[i * c + ch];
+  const float sc = params[i * 2 * c + ch];
+  const float mu = params[i * 2 * c + c + ch];
+  bool over = false;
+  for (int q = 0; q < nq; ++q) {
+    const float s = scale[q * c + ch];
+    const float v = rintf(__fsub_rn(__fmul_rn(yv, s), __fmul_rn(mu, s)));
+    over |= !(v >= -32768.0f && v <= 32767.0f);
+    sym[(int64_t)q * n * c + t] = (int16_t)(int32_t)v;
+    idx[(int64_t)q * n * c + t] = (uint8_t)scale_index(__fmul_rn(sc, s), tab, n_tab);
+  }
+  if (over) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void k_gaussian_indexes8(const float* __restrict__ params, int64_t n,
+                                                           int c, const float* __restrict__ scale,
+                                                           const float* __restrict__ table, int n_tab,
+                                                           uint8_t* __restrict__ idx) {
+  __shared__ float tab[64];
+  if (threadIdx.x < n_tab) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  const int ch = (int)(t / n);
+  const int64_t i = t - (int64_t)ch * n;
+  idx[t] = (uint8_t)scale_index(__fmul_rn(params[i * 2 * c + ch], scale[ch]), tab, n_tab);
+}
+
 __global__ __launch_bounds__(256) void k_gaussian_indexes(const float* __restrict__ params, int64_t n,
                                                           int c, const float* __restrict__ scale,
                                                           const float* __restrict__ table, int n_tab,
@@ -139,6 +180,32 @@ extern "C" int pcc_gaussian_quant(pcc_ctx* ctx, const float* d_y, const float* d
               "pcc_gaussian_quant: null buffers");
   hipLaunchKernelGGL(k_gaussian_quant, dim3(nblk(n * c, 256)), dim3(256), 0, ctx->stream, d_y, d_params,
                      n, c, d_scale, q, d_table, n_tab, d_sym, d_idx);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gaussian_quant16(pcc_ctx* ctx, const float* d_y, const float* d_params, int64_t n,
+                                    int c, const float* d_scale, int q, const float* d_table, int n_tab,
+                                    int16_t* d_sym, uint8_t* d_idx, int32_t* d_flag) {
+  PCC_REQUIRE(ctx && c >= 1 && q >= 1 && n_tab >= 2 && n_tab <= 64, PCC_E_ARG,
+              "pcc_gaussian_quant16: bad arg (c=%d q=%d n_tab=%d)", c, q, n_tab);
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_y && d_params && d_scale && d_table && d_sym && d_idx && d_flag, PCC_E_ARG,
+              "pcc_gaussian_quant16: null buffers");
+  hipLaunchKernelGGL(k_gaussian_quant16, dim3(nblk(n * c, 256)), dim3(256), 0, ctx->stream, d_y, d_params,
+                     n, c, d_scale, q, d_table, n_tab, d_sym, d_idx, d_flag);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gaussian_indexes8(pcc_ctx* ctx, const float* d_params, int64_t n, int c,
+                                     const float* d_scale, const float* d_table, int n_tab,
+                                     uint8_t* d_idx) {
+  PCC_REQUIRE(ctx && c >= 1 && n_tab >= 2 && n_tab <= 64, PCC_E_ARG, "pcc_gaussian_indexes8: bad arg");
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_params && d_scale && d_table && d_idx, PCC_E_ARG, "pcc_gaussian_indexes8: null buffers");
+  hipLaunchKernelGGL(k_gaussian_indexes8, dim3(nblk(n * c, 256)), dim3(256), 0, ctx->stream, d_params, n,
+                     c, d_scale, d_table, n_tab, d_idx);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

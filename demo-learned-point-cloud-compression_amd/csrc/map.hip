@@ -106,6 +106,114 @@ __global__ void k_lookup(const uint64_t* __restrict__ qkeys, int64_t m,
   rows[i] = hash_find(tk, tv, mask, qkeys[i]);
 }
 
+// ---- rule books derived from the parent level's rule book (no hashing) -------
+// A child voxel (parent p, octant o) has its neighbour at offset d in the child
+// of parent-neighbour p + D with octant o', where per axis t = o + d, D =
+// floor(t/2), o' = t mod 2.  So nbr_child[k][c] is two table lookups.
+__device__ __forceinline__ void child_step(int o, int k, int* kp, int* op) {
+  const int ox = (o >> 2) & 1, oy = (o >> 1) & 1, oz = o & 1;
+  const int tx = ox + (k / 9) - 1, ty = oy + ((k / 3) % 3) - 1, tz = oz + (k % 3) - 1;
+  *kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
+  *op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+}
+
+// generative children (all 8 exist): child row = 8 * parent row + octant.
+// parent_rows / remap translate between the pruned parent level (rows j) and the
+// candidate level its rule book was built on: prow = parent_rows[j], and a
+// neighbour candidate row r maps back to the pruned row remap[r] (or -1).
+__global__ __launch_bounds__(256) void k_derive_up(const int32_t* __restrict__ nbr_p, int64_t pitch_p,
+                                                   const uint32_t* __restrict__ parent_rows,
+                                                   const int32_t* __restrict__ remap, int64_t n_par,
+                                                   int32_t* __restrict__ nbr) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nc = n_par * 8;
+  if (c >= nc) return;
+  const int64_t j = c >> 3;
+  const int o = (int)(c & 7);
+  const int64_t prow = parent_rows ? (int64_t)parent_rows[j] : j;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    int kp, op;
+    child_step(o, k, &kp, &op);
+    int32_t pr = nbr_p[(int64_t)kp * pitch_p + prow];
+    if (pr >= 0 && remap) pr = remap[pr];
+    nbr[(int64_t)k * nc + c] = pr < 0 ? -1 : ((pr << 3) | op);
+  }
+}
+
+// children given by a stride-2 map (parent_of, nbr8): second lookup through nbr8
+__global__ __launch_bounds__(256) void k_derive_down(const int32_t* __restrict__ nbr_p, int64_t n_par,
+                                                     const int32_t* __restrict__ nbr8,
+                                                     const int32_t* __restrict__ parent_of,
+                                                     const uint64_t* __restrict__ keys, int64_t n, int cshift,
+                                                     int32_t* __restrict__ nbr) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int64_t p = parent_of[c];
+  const int o = (int)((keys[c] >> cshift) & 7ull);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    int kp, op;
+    child_step(o, k, &kp, &op);
+    const int32_t pr = nbr_p[(int64_t)kp * n_par + p];
+    nbr[(int64_t)k * n + c] = pr < 0 ? -1 : nbr8[(int64_t)op * n_par + pr];
+  }
+}
+
+__global__ void k_fill_neg1(int32_t* __restrict__ p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = -1;
+}
+__global__ void k_inverse_rows(const uint32_t* __restrict__ rows, int64_t m, int32_t* __restrict__ remap) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) remap[rows[j]] = (int32_t)j;
+}
+
+extern "C" int pcc_derive_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t parent_pitch,
+                                 const uint32_t* d_parent_rows, const int32_t* d_remap, int64_t n_parents,
+                                 int32_t* d_nbr) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_derive_map_up: null ctx");
+  if (n_parents <= 0) return PCC_OK;
+  PCC_REQUIRE(d_nbr_parent && d_nbr && parent_pitch >= 1, PCC_E_ARG, "pcc_derive_map_up: bad buffers");
+  PCC_REQUIRE((d_parent_rows == nullptr) == (d_remap == nullptr), PCC_E_ARG,
+              "pcc_derive_map_up: parent_rows and remap go together");
+  PCC_REQUIRE(n_parents < ((int64_t)1 << 27), PCC_E_ARG, "pcc_derive_map_up: n too large");
+  PccProfScope prof(ctx, "derive_map_up", n_parents * 8, parent_pitch, d_remap ? 1 : 0, 27);
+  hipLaunchKernelGGL(k_derive_up, dim3(nblk(n_parents * 8, 256)), dim3(256), 0, ctx->stream, d_nbr_parent,
+                     parent_pitch, d_parent_rows, d_remap, n_parents, d_nbr);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_derive_map_down(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t n_parent,
+                                   const int32_t* d_nbr8, const int32_t* d_parent_of, const uint64_t* d_keys,
+                                   int64_t n, int child_shift, int32_t* d_nbr) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_derive_map_down: null ctx");
+  PCC_REQUIRE(child_shift >= 0 && child_shift <= 42 && child_shift % 3 == 0, PCC_E_ARG,
+              "pcc_derive_map_down: child_shift=%d", child_shift);
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_nbr_parent && d_nbr8 && d_parent_of && d_keys && d_nbr && n_parent >= 1, PCC_E_ARG,
+              "pcc_derive_map_down: bad buffers");
+  PccProfScope prof(ctx, "derive_map_down", n, n_parent, 0, 27);
+  hipLaunchKernelGGL(k_derive_down, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_nbr_parent, n_parent,
+                     d_nbr8, d_parent_of, d_keys, n, child_shift, d_nbr);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_inverse_rows(pcc_ctx* ctx, const uint32_t* d_rows, int64_t m, int64_t n, int32_t* d_remap) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_inverse_rows: null ctx");
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_remap && (m == 0 || d_rows) && m <= n, PCC_E_ARG, "pcc_inverse_rows: bad buffers");
+  hipLaunchKernelGGL(k_fill_neg1, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_remap, n);
+  PCC_CHECK_LAUNCH();
+  if (m > 0) {
+    hipLaunchKernelGGL(k_inverse_rows, dim3(nblk(m, 256)), dim3(256), 0, ctx->stream, d_rows, m, d_remap);
+    PCC_CHECK_LAUNCH();
+  }
+  return PCC_OK;
+}
+
 static int64_t hash_capacity(int64_t n) {
   int64_t cap = 1024;
   while (cap < 2 * n) cap <<= 1;

@@ -27,7 +27,8 @@ __global__ void k_fill_i32(int32_t* __restrict__ p, int64_t n, int32_t v) {
 
 __global__ void k_emit_parents(const uint64_t* __restrict__ keys, int64_t n, int cshift,
                                const uint32_t* __restrict__ flags, const uint32_t* __restrict__ excl,
-                               uint64_t* __restrict__ pkeys, int32_t* __restrict__ nbr8, int64_t m) {
+                               uint64_t* __restrict__ pkeys, int32_t* __restrict__ nbr8, int64_t m,
+                               int32_t* __restrict__ parent_of /*nullable*/) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t k = keys[i];
@@ -36,6 +37,7 @@ __global__ void k_emit_parents(const uint64_t* __restrict__ keys, int64_t n, int
   const int o = (int)((k >> cshift) & 7ull);
   if (f) pkeys[p] = (k >> (cshift + 3)) << (cshift + 3);
   nbr8[(int64_t)o * m + p] = (int32_t)i;
+  if (parent_of) parent_of[i] = (int32_t)p;
 }
 
 __global__ void k_up_keys(const uint64_t* __restrict__ keys, int64_t n, int cshift,
@@ -47,7 +49,7 @@ __global__ void k_up_keys(const uint64_t* __restrict__ keys, int64_t n, int cshi
 
 extern "C" int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift,
                                uint64_t* d_pkeys, int32_t* d_nbr8, int64_t n_cap,
-                               int64_t* h_n_out) {
+                               int32_t* d_parent_of, int64_t* h_n_out) {
   PCC_REQUIRE(ctx && h_n_out, PCC_E_ARG, "pcc_down_coords: null arg");
   PCC_REQUIRE(child_shift >= 0 && child_shift <= 42 && child_shift % 3 == 0, PCC_E_ARG,
               "pcc_down_coords: child_shift=%d", child_shift);
@@ -73,7 +75,7 @@ extern "C" int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, 
   hipLaunchKernelGGL(k_fill_i32, dim3(nblk(8 * m, 256)), dim3(256), 0, st, d_nbr8, 8 * m, -1);
   PCC_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_emit_parents, dim3(nblk(n, 256)), dim3(256), 0, st, d_keys, n, child_shift,
-                     (const uint32_t*)flags, (const uint32_t*)excl, d_pkeys, d_nbr8, m);
+                     (const uint32_t*)flags, (const uint32_t*)excl, d_pkeys, d_nbr8, m, d_parent_of);
   PCC_CHECK_LAUNCH();
   *h_n_out = m;
   return PCC_OK;

@@ -14,6 +14,13 @@
 // The stream is inherently serial, which is why it stays on the host while the
 // GPU forms symbols and indexes (entropy.hip); the Q quality streams of one GOP
 // are independent and are coded on Q threads.
+//
+// Two element widths cross the boundary: int32 symbols / int32 indexes (generic)
+// and int16 symbols / uint8 indexes (what the device kernels emit for the y
+// latents: 3 instead of 8 bytes per symbol over PCIe).  The decoder resolves the
+// symbol with a 256-entry per-table lookup on the top 8 bits of the cumulative
+// frequency followed by a short forward scan (same result as CompressAI's linear
+// std::find_if over the CDF).
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
@@ -60,142 +67,78 @@ inline int n_nibbles(uint32_t raw) {
   return nb;
 }
 
-// number of coder steps a symbol expands to (1 + escape nibbles)
-inline int64_t steps_for(int32_t sym, int32_t offset, int32_t max_value) {
-  int32_t value = sym - offset;
-  uint32_t raw;
-  if (value < 0) raw = (uint32_t)(-2 * (int64_t)value - 1);
-  else if (value >= max_value) raw = (uint32_t)(2 * ((int64_t)value - max_value));
-  else return 1;
-  const int nb = n_nibbles(raw);
-  return 1 + (nb / (int)kMaxBypass + 1) + nb;
-}
-
-int encode_stream(const int32_t* sym, const int32_t* idx, int64_t n, const int32_t* cdfs, int pitch,
+template <typename SymT, typename IdxT>
+int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cdfs, int pitch,
                   const int32_t* sizes, const int32_t* offsets, int n_cdf, uint8_t* out, int64_t cap,
                   int64_t* len, char* err, size_t errlen) {
-  int64_t steps = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    const int32_t ci = idx[i];
-    if (ci < 0 || ci >= n_cdf) {
-      snprintf(err, errlen, "rans encode: index %d out of range at %lld", ci, (long long)i);
-      return PCC_E_ARG;
+  // worst case per symbol: 1 main step + (1..2 unary) + 8 raw nibbles; each step emits at most
+  // one 32-bit word, and in-range symbols (the common case) emit 16 bits on average.  Size the
+  // staging buffer for the common case and grow on demand.
+  std::vector<uint32_t> buf((size_t)(n / 2 + n / 8) + 1024);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    Enc e;
+    e.x = kRansL;
+    e.floor = buf.data();
+    e.ptr = buf.data() + buf.size();
+    e.overflow = false;
+    for (int64_t i = n - 1; i >= 0; --i) {
+      const int32_t ci = (int32_t)idx[i];
+      if ((uint32_t)ci >= (uint32_t)n_cdf) {
+        snprintf(err, errlen, "rans encode: index %d out of range at %lld", ci, (long long)i);
+        return PCC_E_ARG;
+      }
+      const int32_t* cdf = cdfs + (int64_t)ci * pitch;
+      const int32_t max_value = sizes[ci] - 2;
+      int32_t value = (int32_t)sym[i] - offsets[ci];
+      if ((uint32_t)value >= (uint32_t)max_value) {
+        // escape: forward order is main, unary(n_bypass) nibbles, raw nibbles LSB first;
+        // the encoder consumes that list back to front
+        uint32_t raw;
+        if (value < 0) raw = (uint32_t)(-2 * (int64_t)value - 1);
+        else raw = (uint32_t)(2 * ((int64_t)value - max_value));
+        value = max_value;
+        const int nb = n_nibbles(raw);
+        for (int j = nb - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypass);
+        const int full = nb / (int)kMaxBypass;  // number of 15-valued nibbles
+        e.put_bits((uint32_t)(nb - full * (int)kMaxBypass));
+        for (int j = 0; j < full; ++j) e.put_bits(kMaxBypass);
+      }
+      const uint32_t start = (uint32_t)cdf[value];
+      const uint32_t freq = (uint32_t)(cdf[value + 1] - cdf[value]);
+      if (freq == 0) {
+        snprintf(err, errlen, "rans encode: zero frequency (cdf %d, value %d)", ci, value);
+        return PCC_E_ARG;
+      }
+      e.put(start, freq);
     }
-    steps += steps_for(sym[i], offsets[ci], sizes[ci] - 2);
-  }
-  std::vector<uint32_t> buf((size_t)steps + 4);
-  Enc e;
-  e.x = kRansL;
-  e.floor = buf.data();
-  e.ptr = buf.data() + buf.size();
-  e.overflow = false;
-  for (int64_t i = n - 1; i >= 0; --i) {
-    const int32_t ci = idx[i];
-    const int32_t* cdf = cdfs + (int64_t)ci * pitch;
-    const int32_t max_value = sizes[ci] - 2;
-    int32_t value = sym[i] - offsets[ci];
-    uint32_t raw = 0;
-    bool esc = false;
-    if (value < 0) {
-      raw = (uint32_t)(-2 * (int64_t)value - 1);
-      value = max_value;
-      esc = true;
-    } else if (value >= max_value) {
-      raw = (uint32_t)(2 * ((int64_t)value - max_value));
-      value = max_value;
-      esc = true;
+    // flush: two words, low then high
+    e.emit((uint32_t)(e.x >> 32));
+    e.emit((uint32_t)(e.x >> 0));
+    if (e.overflow) {
+      buf.assign((size_t)n * 12 + 1024, 0u);  // absolute worst case
+      continue;
     }
-    if (esc) {
-      // forward order: main, unary(n_bypass) nibbles, raw nibbles LSB first;
-      // the encoder consumes that list back to front
-      const int nb = n_nibbles(raw);
-      for (int j = nb - 1; j >= 0; --j) e.put_bits((raw >> (j * kBypassBits)) & kMaxBypass);
-      const int full = nb / (int)kMaxBypass;          // number of 15-valued nibbles
-      e.put_bits((uint32_t)(nb - full * (int)kMaxBypass));
-      for (int j = 0; j < full; ++j) e.put_bits(kMaxBypass);
+    const int64_t nbytes = (int64_t)((buf.data() + buf.size()) - e.ptr) * 4;
+    if (nbytes > cap) {
+      snprintf(err, errlen, "rans encode: output needs %lld bytes, capacity %lld", (long long)nbytes,
+               (long long)cap);
+      return PCC_E_NOMEM;
     }
-    const uint32_t start = (uint32_t)cdf[value];
-    const uint32_t freq = (uint32_t)(cdf[value + 1] - cdf[value]);
-    if (freq == 0) {
-      snprintf(err, errlen, "rans encode: zero frequency (cdf %d, value %d)", ci, value);
-      return PCC_E_ARG;
-    }
-    e.put(start, freq);
+    memcpy(out, e.ptr, (size_t)nbytes);  // little-endian u32 words, as CompressAI returns them
+    *len = nbytes;
+    return PCC_OK;
   }
-  // flush: two words, low then high
-  e.emit((uint32_t)(e.x >> 32));
-  e.emit((uint32_t)(e.x >> 0));
-  if (e.overflow) {
-    snprintf(err, errlen, "rans encode: internal buffer overflow");
-    return PCC_E_NOMEM;
-  }
-  const int64_t nbytes = (int64_t)((buf.data() + buf.size()) - e.ptr) * 4;
-  if (nbytes > cap) {
-    snprintf(err, errlen, "rans encode: output needs %lld bytes, capacity %lld", (long long)nbytes,
-             (long long)cap);
-    return PCC_E_NOMEM;
-  }
-  memcpy(out, e.ptr, (size_t)nbytes);  // little-endian u32 words, as CompressAI returns them
-  *len = nbytes;
-  return PCC_OK;
+  snprintf(err, errlen, "rans encode: internal buffer overflow");
+  return PCC_E_NOMEM;
 }
 
-struct Dec {
-  uint64_t x;
-  const uint8_t* p;
-  const uint8_t* end;
-  bool bad;
-  inline uint32_t word() {
-    if (end - p < 4) { bad = true; return 0; }
-    uint32_t w;
-    memcpy(&w, p, 4);
-    p += 4;
-    return w;
-  }
-  inline void init() {
-    const uint64_t lo = word();
-    const uint64_t hi = word();
-    x = lo | (hi << 32);
-  }
-  inline uint32_t get() const { return (uint32_t)(x & ((1u << kPrecision) - 1)); }
-  inline void advance(uint32_t start, uint32_t freq) {
-    const uint64_t mask = (1ull << kPrecision) - 1;
-    x = (uint64_t)freq * (x >> kPrecision) + (x & mask) - start;
-    if (x < kRansL) x = (x << 32) | word();
-  }
-  inline uint32_t get_bits() {
-    const uint32_t val = (uint32_t)(x & kMaxBypass);
-    x >>= kBypassBits;
-    if (x < kRansL) x = (x << 32) | word();
-    return val;
-  }
-};
-
-}  // namespace
-
-extern "C" int pcc_rans_encode(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
-                               const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
-                               const int32_t* h_offsets, int n_cdf, uint8_t* h_out, int64_t cap,
-                               int64_t* h_len) {
-  if (!h_len || n < 0 || (n > 0 && (!h_sym || !h_idx)) || !h_cdfs || !h_sizes || !h_offsets || !h_out ||
-      cdf_pitch < 2 || n_cdf < 1) {
-    pcc_set_error("pcc_rans_encode: bad argument");
-    return PCC_E_ARG;
-  }
-  char err[256] = "";
-  const int r = encode_stream(h_sym, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out, cap,
-                              h_len, err, sizeof(err));
-  if (r != PCC_OK) pcc_set_error("%s", err);
-  return r;
-}
-
-extern "C" int pcc_rans_encode_multi(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
-                                     int n_streams, const int32_t* h_cdfs, int cdf_pitch,
-                                     const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
-                                     uint8_t* h_out, int64_t cap_each, int64_t* h_lens) {
+template <typename SymT, typename IdxT>
+int encode_multi(const SymT* h_sym, const IdxT* h_idx, int64_t n, int n_streams, const int32_t* h_cdfs,
+                 int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, uint8_t* h_out,
+                 int64_t cap_each, int64_t* h_lens, const char* who) {
   if (n_streams < 1 || n_streams > 64 || !h_lens || n < 0 || (n > 0 && (!h_sym || !h_idx)) || !h_cdfs ||
       !h_sizes || !h_offsets || !h_out || cdf_pitch < 2 || n_cdf < 1) {
-    pcc_set_error("pcc_rans_encode_multi: bad argument");
+    pcc_set_error("%s: bad argument", who);
     return PCC_E_ARG;
   }
   std::vector<int> rc((size_t)n_streams, PCC_OK);
@@ -211,66 +154,144 @@ extern "C" int pcc_rans_encode_multi(const int32_t* h_sym, const int32_t* h_idx,
   for (auto& t : th) t.join();
   for (int s = 0; s < n_streams; ++s)
     if (rc[s] != PCC_OK) {
-      pcc_set_error("stream %d: %s", s, errs[s].data());
+      pcc_set_error("%s stream %d: %s", who, s, errs[s].data());
       return rc[s];
     }
   return PCC_OK;
 }
 
-extern "C" int pcc_rans_decode(const uint8_t* h_in, int64_t len, const int32_t* h_idx, int64_t n,
-                               const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
-                               const int32_t* h_offsets, int n_cdf, int32_t* h_sym) {
+struct DecTab {
+  const int32_t* cdf;
+  int32_t size, max_value, offset;
+  bool built;
+  uint16_t lut[256];
+};
+
+template <typename IdxT>
+int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n, const int32_t* h_cdfs,
+                  int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, int32_t* h_sym,
+                  const char* who) {
   if (!h_in || len < 8 || n < 0 || (n > 0 && (!h_idx || !h_sym)) || !h_cdfs || !h_sizes || !h_offsets ||
       cdf_pitch < 2 || n_cdf < 1) {
-    pcc_set_error("pcc_rans_decode: bad argument (len=%lld)", (long long)len);
+    pcc_set_error("%s: bad argument (len=%lld)", who, (long long)len);
     return len < 8 ? PCC_E_STREAM : PCC_E_ARG;
   }
-  Dec d;
-  d.p = h_in;
-  d.end = h_in + len;
-  d.bad = false;
-  d.init();
+  std::vector<DecTab> tabs((size_t)n_cdf);
+  for (int c = 0; c < n_cdf; ++c) {
+    tabs[c].cdf = h_cdfs + (int64_t)c * cdf_pitch;
+    tabs[c].size = h_sizes[c];
+    tabs[c].max_value = h_sizes[c] - 2;
+    tabs[c].offset = h_offsets[c];
+    tabs[c].built = false;
+  }
+  const uint8_t* p = h_in;
+  const uint8_t* const end = h_in + len;
+  auto word = [&](bool& bad) -> uint32_t {
+    if (end - p < 4) { bad = true; return 0; }
+    uint32_t w;
+    memcpy(&w, p, 4);
+    p += 4;
+    return w;
+  };
+  bool bad = false;
+  uint64_t x = word(bad);
+  x |= (uint64_t)word(bad) << 32;
   for (int64_t i = 0; i < n; ++i) {
-    const int32_t ci = h_idx[i];
-    if (ci < 0 || ci >= n_cdf) {
-      pcc_set_error("pcc_rans_decode: index %d out of range at %lld", ci, (long long)i);
+    const int32_t ci = (int32_t)h_idx[i];
+    if ((uint32_t)ci >= (uint32_t)n_cdf) {
+      pcc_set_error("%s: index %d out of range at %lld", who, ci, (long long)i);
       return PCC_E_ARG;
     }
-    const int32_t* cdf = h_cdfs + (int64_t)ci * cdf_pitch;
-    const int32_t size = h_sizes[ci];
-    const int32_t max_value = size - 2;
-    const uint32_t cum = d.get();
-    // first entry > cum, minus one (CompressAI: std::find_if over the CDF)
-    const int32_t* it = std::upper_bound(cdf, cdf + size, (int32_t)cum);
-    int32_t s = (int32_t)(it - cdf) - 1;
-    if (s < 0 || s > max_value) {
-      pcc_set_error("pcc_rans_decode: corrupt stream at symbol %lld", (long long)i);
-      return PCC_E_STREAM;
+    DecTab& t = tabs[ci];
+    if (!t.built) {
+      if (t.size < 2 || t.size > cdf_pitch) {
+        pcc_set_error("%s: cdf %d has length %d", who, ci, t.size);
+        return PCC_E_ARG;
+      }
+      // lut[b] = largest s with cdf[s] <= b<<8
+      int s = 0;
+      for (int b = 0; b < 256; ++b) {
+        while (s + 1 < t.size - 1 && t.cdf[s + 1] <= (b << 8)) ++s;
+        t.lut[b] = (uint16_t)s;
+      }
+      t.built = true;
     }
-    d.advance((uint32_t)cdf[s], (uint32_t)(cdf[s + 1] - cdf[s]));
+    const uint32_t cum = (uint32_t)(x & 0xFFFFu);
+    int32_t s = t.lut[cum >> 8];
+    while (s < t.max_value && (uint32_t)t.cdf[s + 1] <= cum) ++s;  // == find_if(v > cum) - 1
+    const uint32_t start = (uint32_t)t.cdf[s];
+    const uint32_t freq = (uint32_t)(t.cdf[s + 1] - t.cdf[s]);
+    x = (uint64_t)freq * (x >> kPrecision) + cum - start;
+    if (x < kRansL) x = (x << 32) | word(bad);
     int32_t value = s;
-    if (value == max_value) {
-      int32_t val = (int32_t)d.get_bits();
+    if (value == t.max_value) {
+      auto get_bits = [&]() -> uint32_t {
+        const uint32_t v = (uint32_t)(x & kMaxBypass);
+        x >>= kBypassBits;
+        if (x < kRansL) x = (x << 32) | word(bad);
+        return v;
+      };
+      int32_t val = (int32_t)get_bits();
       int32_t n_bypass = val;
-      while (val == (int32_t)kMaxBypass && !d.bad) {
-        val = (int32_t)d.get_bits();
+      while (val == (int32_t)kMaxBypass && !bad) {
+        val = (int32_t)get_bits();
         n_bypass += val;
       }
       if (n_bypass > 8) {  // a 32-bit raw value has at most 8 nibbles
-        pcc_set_error("pcc_rans_decode: corrupt escape at symbol %lld", (long long)i);
+        pcc_set_error("%s: corrupt escape at symbol %lld", who, (long long)i);
         return PCC_E_STREAM;
       }
       uint32_t raw = 0;
-      for (int j = 0; j < n_bypass; ++j) raw |= d.get_bits() << (j * kBypassBits);
+      for (int j = 0; j < n_bypass; ++j) raw |= get_bits() << (j * kBypassBits);
       value = (int32_t)(raw >> 1);
       if (raw & 1u) value = -value - 1;
-      else value += max_value;
+      else value += t.max_value;
     }
-    if (d.bad) {
-      pcc_set_error("pcc_rans_decode: truncated stream at symbol %lld", (long long)i);
+    if (bad) {
+      pcc_set_error("%s: truncated stream at symbol %lld", who, (long long)i);
       return PCC_E_STREAM;
     }
-    h_sym[i] = value + h_offsets[ci];
+    h_sym[i] = value + t.offset;
   }
   return PCC_OK;
+}
+
+}  // namespace
+
+extern "C" int pcc_rans_encode(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
+                               const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                               const int32_t* h_offsets, int n_cdf, uint8_t* h_out, int64_t cap,
+                               int64_t* h_len) {
+  return encode_multi(h_sym, h_idx, n, 1, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out, cap, h_len,
+                      "pcc_rans_encode");
+}
+
+extern "C" int pcc_rans_encode_multi(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
+                                     int n_streams, const int32_t* h_cdfs, int cdf_pitch,
+                                     const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                                     uint8_t* h_out, int64_t cap_each, int64_t* h_lens) {
+  return encode_multi(h_sym, h_idx, n, n_streams, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out,
+                      cap_each, h_lens, "pcc_rans_encode_multi");
+}
+
+extern "C" int pcc_rans_encode_multi16(const int16_t* h_sym, const uint8_t* h_idx, int64_t n,
+                                       int n_streams, const int32_t* h_cdfs, int cdf_pitch,
+                                       const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                                       uint8_t* h_out, int64_t cap_each, int64_t* h_lens) {
+  return encode_multi(h_sym, h_idx, n, n_streams, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out,
+                      cap_each, h_lens, "pcc_rans_encode_multi16");
+}
+
+extern "C" int pcc_rans_decode(const uint8_t* h_in, int64_t len, const int32_t* h_idx, int64_t n,
+                               const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                               const int32_t* h_offsets, int n_cdf, int32_t* h_sym) {
+  return decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
+                       "pcc_rans_decode");
+}
+
+extern "C" int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n,
+                                const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                                const int32_t* h_offsets, int n_cdf, int32_t* h_sym) {
+  return decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
+                       "pcc_rans_decode8");
 }

@@ -28,8 +28,11 @@ class _Coder:
         return _rt.rans_encode_multi(np.ascontiguousarray(sym), np.ascontiguousarray(idx), self.cdf, self.length,
                                      self.offset)
 
-    def decode(self, data, idx):
-        return _rt.rans_decode(data, np.ascontiguousarray(idx, dtype=np.int32), self.cdf, self.length, self.offset)
+    def decode(self, data, idx, out=None):
+        idx = np.ascontiguousarray(idx)
+        if idx.dtype != np.uint8:
+            idx = idx.astype(np.int32, copy=False)
+        return _rt.rans_decode(data, idx, self.cdf, self.length, self.offset, out=out)
 
 
 class EntropyBottleneck:
@@ -89,17 +92,25 @@ class GaussianConditional:
     # fused forms used by the pipeline ------------------------------------
     def compress_rows(self, rt, y_rows, params_rows, scale_q):
         """y_rows [N,C], params_rows [N,2C], scale_q device [Q,C] -> Q byte strings"""
-        sym, idx = rt.gaussian_quant(y_rows, params_rows, scale_q, self.scale_table)
         q = scale_q.shape[0]
-        sym_h = sym.cpu().numpy().reshape(q, -1)
-        idx_h = idx.cpu().numpy().reshape(q, -1)
-        return self.coder.encode(sym_h, idx_h)
+        sym, idx, flag = rt.gaussian_quant16(y_rows, params_rows, scale_q, self.scale_table)
+        sym_h = rt.to_host_async(sym, "y_sym")
+        idx_h = rt.to_host_async(idx, "y_idx")
+        flag_h = rt.to_host_async(flag, "y_flag")
+        rt.sync()
+        if int(flag_h[0]) != 0:     # a symbol outside int16: take the generic int32 form
+            sym, idx = rt.gaussian_quant(y_rows, params_rows, scale_q, self.scale_table)
+            sym_h, idx_h = sym.cpu().numpy(), idx.cpu().numpy()
+        return self.coder.encode(sym_h.reshape(q, -1), idx_h.reshape(q, -1))
 
     def decompress_rows(self, rt, string, params_rows, scale_1, off_a, off_b):
         """one quality: returns y_hat rows [N,C] (offset de-quantisation applied)"""
         n, c = params_rows.shape[0], params_rows.shape[1] // 2
-        idx = rt.gaussian_indexes(params_rows, scale_1, self.scale_table)
-        sym = self.coder.decode(string, idx.cpu().numpy().reshape(-1))
-        sym_d = rt.to_device(sym.reshape(c, n), torch.int32)
+        idx = rt.gaussian_indexes8(params_rows, scale_1, self.scale_table)
+        idx_h = rt.to_host_async(idx, "y_idx")
+        rt.sync()
+        stage = rt.pinned("y_dec", 4 * c * n)[:4 * c * n].view(torch.int32)
+        self.coder.decode(string, idx_h.reshape(-1), out=stage.numpy())
+        sym_d = rt.from_pinned_async(stage).view(c, n)
         return rt.gaussian_dequant(sym_d, params_rows, scale_1, float(self.scale_bound), float(off_a),
                                    float(off_b))

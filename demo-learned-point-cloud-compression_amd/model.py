@@ -55,7 +55,7 @@ def conv3(p, name, x, relu):
 def down2(p, name, x, relu):
     rt = x.rt
     w, b = p.wb(name)
-    pcs, nbr8 = x.cs.down()
+    pcs, nbr8, _ = x.cs.down()
     return SparseTensor(rt.sparse_conv(x.F, nbr8, w, b, relu), coordset=pcs)
 
 
@@ -102,7 +102,7 @@ class SynthesisTransform:
 
     def down_conv(self, st):
         # only the output coordinate set is consumed (codec_parallel.py:302-305)
-        pcs, _ = st.cs.down()
+        pcs = st.cs.down()[0]
         return SparseTensor(None, coordset=pcs)
 
     def __call__(self, y_hat, k):

@@ -8,6 +8,7 @@ One Runtime per in-flight compress()/decompress() call (the reference runs up
 to three concurrent calls, sender/encoder/encoder.py:50).
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -17,6 +18,12 @@ from . import _abi
 from ._abi import check, PccError
 
 _tls = threading.local()
+
+# Host thread pools must fit the CPU share of the box (see _abi.host_cpu_budget): the codec's
+# host side is a handful of short tensor conversions, so a small intra-op pool is enough.
+HOST_THREADS = int(os.environ.get("PCC_HOST_THREADS", "0")) or min(8, _abi.host_cpu_budget())
+if torch.get_num_threads() > HOST_THREADS:
+    torch.set_num_threads(HOST_THREADS)
 
 
 def current():
@@ -102,8 +109,9 @@ class Runtime:
         return ms.value
 
     # ------------------------------------------------------------ per-launch profiler
-    def prof_enable(self, on=True):
-        check(self.lib.pcc_prof_enable(self.ctx, 1 if on else 0), "pcc_prof_enable")
+    def prof_enable(self, on=True, reserve=0):
+        """reserve > 1 pre-creates that many event pairs (keeps event creation out of the timed region)"""
+        check(self.lib.pcc_prof_enable(self.ctx, max(int(reserve), 1) if on else 0), "pcc_prof_enable")
 
     def prof_records(self):
         """[(op, ms, (d0,d1,d2,d3)), ...] of every C-ABI call since prof_enable (synchronises)"""
@@ -183,11 +191,33 @@ class Runtime:
         n = keys.shape[0]
         pkeys = self.empty((n,), torch.int64)
         nbr8 = self.empty((8 * n,), torch.int32)
+        parent_of = self.empty((n,), torch.int32)
         m = C.c_int64(0)
         check(self.lib.pcc_down_coords(self.ctx, _ptr(keys), n, child_shift, _ptr(pkeys), _ptr(nbr8), n,
-                                       C.byref(m)), "pcc_down_coords")
+                                       _ptr(parent_of), C.byref(m)), "pcc_down_coords")
         m = m.value
-        return pkeys[:m], nbr8[:8 * m].view(8, m)
+        return pkeys[:m], nbr8[:8 * m].view(8, m), parent_of
+
+    def derive_map_up(self, nbr_parent, n_parents, parent_rows=None, remap=None):
+        nbr = self.empty((27, 8 * n_parents), torch.int32)
+        check(self.lib.pcc_derive_map_up(self.ctx, _ptr(nbr_parent), nbr_parent.stride(0),
+                                         _ptr(parent_rows) if parent_rows is not None else C.c_void_p(0),
+                                         _ptr(remap) if remap is not None else C.c_void_p(0), n_parents,
+                                         _ptr(nbr)), "pcc_derive_map_up")
+        return nbr
+
+    def derive_map_down(self, nbr_parent, nbr8, parent_of, keys, child_shift):
+        n = keys.shape[0]
+        nbr = self.empty((27, n), torch.int32)
+        check(self.lib.pcc_derive_map_down(self.ctx, _ptr(nbr_parent), nbr_parent.shape[1], _ptr(nbr8),
+                                           _ptr(parent_of), _ptr(keys), n, child_shift, _ptr(nbr)),
+              "pcc_derive_map_down")
+        return nbr
+
+    def inverse_rows(self, rows, n):
+        remap = self.empty((n,), torch.int32)
+        check(self.lib.pcc_inverse_rows(self.ctx, _ptr(rows), rows.shape[0], n, _ptr(remap)), "pcc_inverse_rows")
+        return remap
 
     def up_coords(self, keys, child_shift):
         n = keys.shape[0]
@@ -276,6 +306,46 @@ class Runtime:
                                           table.shape[0], _ptr(sym), _ptr(idx)), "pcc_gaussian_quant")
         return sym, idx
 
+    def gaussian_quant16(self, y, params, scale, table):
+        """compact form: int16 symbols, uint8 indexes, overflow flag (device int32[1])"""
+        n, c = y.shape
+        q = scale.shape[0]
+        sym = self.empty((q, c, n), torch.int16)
+        idx = self.empty((q, c, n), torch.uint8)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(self.lib.pcc_gaussian_quant16(self.ctx, _ptr(y), _ptr(params), n, c, _ptr(scale), q, _ptr(table),
+                                            table.shape[0], _ptr(sym), _ptr(idx), _ptr(flag)),
+              "pcc_gaussian_quant16")
+        return sym, idx, flag
+
+    def gaussian_indexes8(self, params, scale, table):
+        n, c = params.shape[0], params.shape[1] // 2
+        idx = self.empty((c, n), torch.uint8)
+        check(self.lib.pcc_gaussian_indexes8(self.ctx, _ptr(params), n, c, _ptr(scale), _ptr(table),
+                                             table.shape[0], _ptr(idx)), "pcc_gaussian_indexes8")
+        return idx
+
+    # ------------------------------------------------------------ pinned staging
+    def pinned(self, key, nbytes):
+        """a cached page-locked host buffer of at least nbytes (uint8 tensor)"""
+        pool = self.__dict__.setdefault("_pin", {})
+        buf = pool.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 4096), dtype=torch.uint8, pin_memory=True)
+            pool[key] = buf
+        return buf
+
+    def to_host_async(self, t, key):
+        """device tensor -> numpy view of a pinned buffer; valid after the next sync()"""
+        nbytes = t.numel() * t.element_size()
+        buf = self.pinned(key, nbytes)[:nbytes].view(t.dtype).view(t.shape)
+        buf.copy_(t, non_blocking=True)
+        return buf.numpy()
+
+    def from_pinned_async(self, host_tensor):
+        """pinned host tensor -> new device tensor (async on this runtime's stream)"""
+        return host_tensor.to(self.device, non_blocking=True)
+
     def gaussian_indexes(self, params, scale, table):
         n, c = params.shape[0], params.shape[1] // 2
         idx = self.empty((c, n), torch.int32)
@@ -304,15 +374,26 @@ class Runtime:
 
 # ---------------------------------------------------------------- host coders (no ctx)
 def rans_encode_multi(sym, idx, cdfs, sizes, offsets):
-    """sym/idx: int32 numpy [S, n]; returns list of S byte strings"""
+    """sym/idx: numpy [S, n], either (int32, int32) or the compact (int16, uint8);
+    returns list of S byte strings"""
     lib = _abi.lib()
     s, n = sym.shape
-    cap = 8 * n + 64
-    out = np.empty((s, cap), dtype=np.uint8)
+    if sym.dtype == np.int16 and idx.dtype == np.uint8:
+        fn, name = lib.pcc_rans_encode_multi16, "pcc_rans_encode_multi16"
+    elif sym.dtype == np.int32 and idx.dtype == np.int32:
+        fn, name = lib.pcc_rans_encode_multi, "pcc_rans_encode_multi"
+    else:
+        raise TypeError(f"rans_encode_multi: unsupported dtypes {sym.dtype}/{idx.dtype}")
     lens = (C.c_int64 * s)()
-    check(lib.pcc_rans_encode_multi(_np_ptr(sym), _np_ptr(idx), n, s, _np_ptr(cdfs), cdfs.shape[1],
-                                    _np_ptr(sizes), _np_ptr(offsets), cdfs.shape[0], _np_ptr(out), cap, lens),
-          "pcc_rans_encode_multi")
+    cap = 2 * n + 4096                      # in-range symbols cost <= 16 bits each
+    for _ in range(2):
+        out = np.empty((s, cap), dtype=np.uint8)
+        rc = fn(_np_ptr(sym), _np_ptr(idx), n, s, _np_ptr(cdfs), cdfs.shape[1], _np_ptr(sizes), _np_ptr(offsets),
+                cdfs.shape[0], _np_ptr(out), cap, lens)
+        if rc != _abi.PCC_E_NOMEM:
+            break
+        cap = 48 * n + 4096                 # escape-heavy input: absolute worst case
+    check(rc, name)
     return [out[i, :lens[i]].tobytes() for i in range(s)]
 
 
@@ -320,13 +401,20 @@ def rans_encode(sym, idx, cdfs, sizes, offsets):
     return rans_encode_multi(sym.reshape(1, -1), idx.reshape(1, -1), cdfs, sizes, offsets)[0]
 
 
-def rans_decode(data, idx, cdfs, sizes, offsets):
+def rans_decode(data, idx, cdfs, sizes, offsets, out=None):
+    """idx: int32 or uint8 numpy [n]; returns int32 symbols (written into `out` if given)"""
     lib = _abi.lib()
     n = idx.shape[0]
     buf = np.frombuffer(data, dtype=np.uint8)
-    sym = np.empty(n, dtype=np.int32)
-    check(lib.pcc_rans_decode(_np_ptr(buf), buf.shape[0], _np_ptr(idx), n, _np_ptr(cdfs), cdfs.shape[1],
-                              _np_ptr(sizes), _np_ptr(offsets), cdfs.shape[0], _np_ptr(sym)), "pcc_rans_decode")
+    sym = out if out is not None else np.empty(n, dtype=np.int32)
+    assert sym.dtype == np.int32 and sym.shape[0] == n
+    if idx.dtype == np.uint8:
+        fn, name = lib.pcc_rans_decode8, "pcc_rans_decode8"
+    else:
+        fn, name = lib.pcc_rans_decode, "pcc_rans_decode"
+        assert idx.dtype == np.int32
+    check(fn(_np_ptr(buf), buf.shape[0], _np_ptr(idx), n, _np_ptr(cdfs), cdfs.shape[1], _np_ptr(sizes),
+             _np_ptr(offsets), cdfs.shape[0], _np_ptr(sym)), name)
     return sym
 
 

@@ -7,11 +7,22 @@ Rows are stored sorted by Morton key (include/pcc.h).  A CoordSet is the
 analogue of a coordinate-map key in ME's coordinate manager: tensors that share
 coordinates share one CoordSet and therefore its cached rule books, parents and
 children.
+
+Rule books (3^3 kernel maps) are built with the coordinate hash only at the
+coarsest level of a pyramid; every finer level derives its rule book from its
+parent's with table lookups (csrc/map.hip, pcc_derive_map_*):
+  - generative children (`up()`), also when the parent level is a top-k pruned
+    subset of its own candidate level (`subset()`);
+  - levels linked by a stride-2 map (`down()`).
 """
+import weakref
+
 import numpy as np
 import torch
 
 from . import runtime as _rt
+
+HASH_BUILD_MAX = 60000      # levels up to this many voxels hash directly; larger ones derive
 
 
 def _log2(ts):
@@ -29,8 +40,10 @@ class CoordSet:
         self.n = int(keys.shape[0])
         self._coords = None
         self._nbr27 = None
-        self._down = None                # (CoordSet, nbr8)
+        self._down = None                # (CoordSet, nbr8, parent_of)
         self._up = None                  # CoordSet
+        self._gen_parent = None          # CoordSet whose generative children these rows are
+        self._subset_of = None           # (candidate CoordSet, keep rows) for a pruned level
         self._n_batch = n_batch
         self._offsets = offsets          # host list, len n_batch+1
 
@@ -58,35 +71,59 @@ class CoordSet:
             self._offsets = self.rt.batch_offsets(self.keys, self.n_batch)
         return self._offsets
 
+    # ------------------------------------------------------------ rule book
     def nbr27(self):
         if self._nbr27 is None:
-            self._nbr27 = self.rt.build_map(self.keys, self.stride)
+            self._nbr27 = self._build_nbr27()
             log = getattr(self.rt, "pairs_log", None)
             if log is not None:     # bench.py: active-pair count of each rule book, keyed by row count
                 log[self.n] = self.rt.count_nonneg(self._nbr27)
         return self._nbr27
 
+    def _build_nbr27(self):
+        rt = self.rt
+        gp = self._gen_parent
+        if gp is not None and gp.n > 0:
+            if gp._nbr27 is None and gp._subset_of is not None:
+                # parent is a pruned subset of its candidate level: go through the candidates' rule book
+                cand, keep = gp._subset_of
+                remap = rt.inverse_rows(keep, cand.n)
+                return rt.derive_map_up(cand.nbr27(), gp.n, keep, remap)
+            return rt.derive_map_up(gp.nbr27(), gp.n)
+        if self.n > HASH_BUILD_MAX and self.stride <= 4096:
+            pcs, nbr8, parent_of = self.down()
+            return rt.derive_map_down(pcs.nbr27(), nbr8, parent_of, self.keys, 3 * _log2(self.stride))
+        return rt.build_map(self.keys, self.stride)
+
+    # ------------------------------------------------------------ pyramid
     def down(self):
-        """parents at stride*2 and the kernel-2 rule book [8, M]"""
+        """parents at stride*2, the kernel-2 rule book [8, M] and the parent row of every row"""
         if self._down is None:
-            pkeys, nbr8 = self.rt.down_coords(self.keys, 3 * _log2(self.stride))
-            self._down = (CoordSet(self.rt, pkeys, self.stride * 2, self._n_batch), nbr8)
+            pkeys, nbr8, parent_of = self.rt.down_coords(self.keys, 3 * _log2(self.stride))
+            self._down = (CoordSet(self.rt, pkeys, self.stride * 2, self._n_batch), nbr8, parent_of)
         return self._down
 
     def up(self):
         """generative children at stride/2: 8 per row, row 8p+o"""
-        if self._up is None:
+        child = self._up() if self._up is not None else None
+        if child is None:
             if self.stride < 2:
                 raise ValueError("cannot up-sample a stride-1 coordinate set")
             ckeys = self.rt.up_coords(self.keys, 3 * (_log2(self.stride) - 1))
             offs = [8 * o for o in self._offsets] if self._offsets is not None else None
-            self._up = CoordSet(self.rt, ckeys, self.stride // 2, self._n_batch, offs)
-        return self._up
+            child = CoordSet(self.rt, ckeys, self.stride // 2, self._n_batch, offs)
+            child._gen_parent = self
+            # weak: the child keeps its parent alive (it derives its rule book from it), not the
+            # other way round — a strong cycle would leave GBs of HBM to the cyclic GC
+            self._up = weakref.ref(child)
+        return child
 
     def subset(self, rows, n_batch=None, offsets=None):
         """stable compaction: keep `rows` (ascending uint32 indices)"""
-        return CoordSet(self.rt, self.rt.gather_rows(self.keys, rows), self.stride,
-                        n_batch if n_batch is not None else self._n_batch, offsets)
+        cs = CoordSet(self.rt, self.rt.gather_rows(self.keys, rows), self.stride,
+                      n_batch if n_batch is not None else self._n_batch, offsets)
+        cs._subset_of = (self, rows)
+        return cs
 
 
 class SparseTensor:

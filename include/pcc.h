@@ -133,18 +133,39 @@ int pcc_batch_offsets(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
 /* replaces: the output coordinate map of every stride-2 kernel-2 convolution
  * (g_a / h_a down stages, g_s.down_conv codec_parallel.py:302-303):
  * parents = unique(floor(c / 2ts) * 2ts).  child_shift = 3*log2(ts).
- * Outputs sized for n rows (upper bound): d_pkeys, d_nbr8 ([8,n_cap] with
- * row pitch n_cap; only the first *h_n_out columns are meaningful).
+ * Outputs: d_pkeys (capacity n_cap >= n), d_nbr8 (capacity 8*n_cap) laid out
+ * [8, M] with row pitch M = *h_n_out, d_parent_of[i] = parent row of input i.
  * Synchronises to return *h_n_out. */
 int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
                     int child_shift, uint64_t* d_pkeys, int32_t* d_nbr8,
-                    int64_t n_cap, int64_t* h_n_out);
+                    int64_t n_cap, int32_t* d_parent_of /* [n], nullable */,
+                    int64_t* h_n_out);
 /* replaces: the generative transposed-convolution coordinate map (up stages
  * of h_s and g_s): children key = parent | o << (3*log2(ts/2)), row 8p+o. */
 int pcc_up_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
                   int child_shift, uint64_t* d_ckeys);
 
 /* ---- rule book (kernel map) and lookup --------------------------------- */
+
+/* The same rule book WITHOUT hashing, derived from the parent level's rule
+ * book: a child (parent p, octant o) has its neighbour at offset d in the child
+ * o' of parent-neighbour p+D with, per axis, t = o+d, D = floor(t/2), o' = t&1.
+ *  - up:   children are the 8 generative children of n_parents rows (child row
+ *          8j+o).  If the parent level is a pruned subset of the level the
+ *          rule book d_nbr_parent was built on, d_parent_rows[j] is its row
+ *          there and d_remap maps rows of that level back to pruned rows (-1
+ *          if dropped); pass both NULL when parent rows == rule-book rows.
+ *  - down: children/parents linked by pcc_down_coords (d_parent_of, d_nbr8).
+ *  - pcc_inverse_rows: remap[rows[j]] = j, -1 elsewhere (n entries). */
+int pcc_derive_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent,
+                      int64_t parent_pitch, const uint32_t* d_parent_rows,
+                      const int32_t* d_remap, int64_t n_parents, int32_t* d_nbr);
+int pcc_derive_map_down(pcc_ctx* ctx, const int32_t* d_nbr_parent,
+                        int64_t n_parent, const int32_t* d_nbr8,
+                        const int32_t* d_parent_of, const uint64_t* d_keys,
+                        int64_t n, int child_shift, int32_t* d_nbr);
+int pcc_inverse_rows(pcc_ctx* ctx, const uint32_t* d_rows, int64_t m, int64_t n,
+                     int32_t* d_remap);
 
 /* replaces: ME kernel-map generation for 3^3 stride-1 convolutions.
  * stride = tensor stride ts; d_nbr is [27, n]. */
@@ -211,6 +232,16 @@ int pcc_gaussian_quant(pcc_ctx* ctx, const float* d_y, const float* d_params,
                        int64_t n, int c, const float* d_scale, int q,
                        const float* d_table, int n_tab, int32_t* d_sym,
                        int32_t* d_idx);
+/* compact form of the same: int16 symbols, uint8 indexes (3 instead of 8 bytes
+ * per symbol across PCIe).  d_flag (int32[1]) is OR-ed with 1 if a symbol does
+ * not fit int16; the caller then falls back to pcc_gaussian_quant. */
+int pcc_gaussian_quant16(pcc_ctx* ctx, const float* d_y, const float* d_params,
+                         int64_t n, int c, const float* d_scale, int q,
+                         const float* d_table, int n_tab, int16_t* d_sym,
+                         uint8_t* d_idx, int32_t* d_flag);
+int pcc_gaussian_indexes8(pcc_ctx* ctx, const float* d_params, int64_t n, int c,
+                          const float* d_scale, const float* d_table, int n_tab,
+                          uint8_t* d_idx);
 /* decoder side (codec_parallel.py:394-409): indexes for one quality */
 int pcc_gaussian_indexes(pcc_ctx* ctx, const float* d_params, int64_t n, int c,
                          const float* d_scale, const float* d_table, int n_tab,
@@ -247,6 +278,18 @@ int pcc_rans_encode_multi(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
                           const int32_t* h_sizes, const int32_t* h_offsets,
                           int n_cdf, uint8_t* h_out, int64_t cap_each,
                           int64_t* h_lens);
+
+/* the same coders for the compact element widths (int16 symbols / uint8
+ * indexes on encode, uint8 indexes on decode) */
+int pcc_rans_encode_multi16(const int16_t* h_sym, const uint8_t* h_idx,
+                            int64_t n, int n_streams, const int32_t* h_cdfs,
+                            int cdf_pitch, const int32_t* h_sizes,
+                            const int32_t* h_offsets, int n_cdf, uint8_t* h_out,
+                            int64_t cap_each, int64_t* h_lens);
+int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx,
+                     int64_t n, const int32_t* h_cdfs, int cdf_pitch,
+                     const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                     int32_t* h_sym);
 
 /* replaces: utils.gpcc_encode / gpcc_decode (shared/utils.py:169-240), i.e.
  * the tmc3 subprocess: lossless octree occupancy coding of one frame's latent

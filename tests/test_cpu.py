@@ -177,6 +177,24 @@ def test_rans_multi_stream_and_empty(oracle):
     assert runtime.rans_decode(e, np.zeros(0, np.int32), cdf, sizes, offs).shape == (0,)
 
 
+def test_rans_compact_widths_equal_generic(oracle):
+    """int16 symbols / uint8 indexes (what the device emits) give the same streams"""
+    runtime = pkg("runtime")
+    cdf, sizes, offs = _tables(oracle, "gaussian_conditional")
+    rng = np.random.default_rng(5)
+    sym = rng.integers(-12, 13, (2, 30000)).astype(np.int32)
+    sym[0, ::501] = 30000
+    sym[1, 7::499] = -30000
+    idx = rng.integers(0, 64, (2, 30000)).astype(np.int32)
+    a = runtime.rans_encode_multi(sym, idx, cdf, sizes, offs)
+    b = runtime.rans_encode_multi(sym.astype(np.int16), idx.astype(np.uint8), cdf, sizes, offs)
+    assert a == b
+    for s in range(2):
+        assert a[s] == oracle.rans_encode(sym[s], idx[s], "gaussian_conditional")
+        assert np.array_equal(runtime.rans_decode(a[s], idx[s].astype(np.uint8), cdf, sizes, offs), sym[s])
+        assert np.array_equal(runtime.rans_decode(a[s], idx[s], cdf, sizes, offs), sym[s])
+
+
 def test_rans_decode_rejects_truncated(oracle):
     runtime = pkg("runtime")
     cdf, sizes, offs = _tables(oracle, "gaussian_conditional")

@@ -101,10 +101,48 @@ def test_down_coords(rt, oracle, clouds, name, stride):
     c = clouds[name].copy()
     c[:, 1:] *= stride
     keys = sorted_keys(oracle, c)
-    pk, nbr8 = rt.down_coords(dev(rt, keys.view(np.int64)), 3 * (stride.bit_length() - 1))
+    pk, nbr8, parent_of = rt.down_coords(dev(rt, keys.view(np.int64)), 3 * (stride.bit_length() - 1))
     rpk, rnbr = oracle.down(keys, stride)
     assert np.array_equal(u64(pk), rpk)
     assert np.array_equal(host(nbr8), rnbr)
+    shift = np.uint64(3 * stride.bit_length())
+    assert np.array_equal(rpk[host(parent_of)], (keys >> shift) << shift)
+
+
+@pytest.mark.parametrize("name,stride", [("surf", 1), ("rand", 2), ("tiny", 1)])
+def test_derived_map_down_equals_hash_map(rt, oracle, clouds, name, stride):
+    """rule book derived from the parent level == rule book from the coordinate hash == oracle"""
+    c = clouds[name].copy()
+    c[:, 1:] *= stride
+    keys = sorted_keys(oracle, c)
+    kd = dev(rt, keys.view(np.int64))
+    cshift = 3 * (stride.bit_length() - 1)
+    pk, nbr8, parent_of = rt.down_coords(kd, cshift)
+    nbr_p = rt.build_map(pk, stride * 2)
+    nbr = rt.derive_map_down(nbr_p, nbr8.contiguous(), parent_of, kd, cshift)
+    assert np.array_equal(host(nbr), oracle.map27(keys, stride))
+
+
+@pytest.mark.parametrize("prune", [False, True])
+def test_derived_map_up_equals_oracle(rt, oracle, clouds, prune):
+    """generative children of a (possibly pruned) parent level"""
+    c = clouds["surf"].copy()
+    c[:, 1:] *= 4
+    cand_keys = sorted_keys(oracle, c)                       # plays the candidate level (stride 4)
+    cand = dev(rt, cand_keys.view(np.int64))
+    nbr_cand = rt.build_map(cand, 4)
+    if prune:
+        rng = np.random.default_rng(0)
+        keep = np.sort(rng.permutation(len(cand_keys))[: len(cand_keys) // 2]).astype(np.uint32)
+        keep_d = dev(rt, keep.view(np.int32))
+        remap = rt.inverse_rows(keep_d, len(cand_keys))
+        par_keys = cand_keys[keep]
+        nbr = rt.derive_map_up(nbr_cand, len(keep), keep_d, remap)
+    else:
+        par_keys = cand_keys
+        nbr = rt.derive_map_up(nbr_cand, len(cand_keys))
+    child_keys = oracle.up(par_keys, 4)
+    assert np.array_equal(host(nbr), oracle.map27(child_keys, 2))
 
 
 def test_up_coords(rt, oracle, clouds):
@@ -264,6 +302,13 @@ def test_gaussian_quant_indexes_dequant(rt, oracle):
     sym, idx = rt.gaussian_quant(dev(rt, y), dev(rt, params), dev(rt, scale), tab)
     rs, ri = oracle.gaussian_quant(y, params, scale)
     assert np.array_equal(host(sym), rs) and np.array_equal(host(idx), ri)
+    s16, i8, flag = rt.gaussian_quant16(dev(rt, y), dev(rt, params), dev(rt, scale), tab)
+    assert int(flag.item()) == 0
+    assert np.array_equal(host(s16).astype(np.int32), rs) and np.array_equal(host(i8).astype(np.int32), ri)
+    _, _, flag2 = rt.gaussian_quant16(dev(rt, y * 1e5), dev(rt, params), dev(rt, scale), tab)
+    assert int(flag2.item()) == 1      # symbols beyond int16 are flagged, the caller falls back to int32
+    assert np.array_equal(host(rt.gaussian_indexes8(dev(rt, params), dev(rt, scale[2]), tab)).astype(np.int32),
+                          ri[2])
     i1 = rt.gaussian_indexes(dev(rt, params), dev(rt, scale[2]), tab)
     assert np.array_equal(host(i1), oracle.gaussian_indexes(params, scale[2]))
     assert np.array_equal(host(i1), ri[2])
