@@ -112,6 +112,119 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma(
   }
 }
 
+// Software-pipelined form for CIN = 32 (the kernel the roofline figure is quoted on).
+//  - the tile's 27 (or 8) neighbour indices are read once, up front, into a wave-private LDS
+//    table and reduced to a wave-uniform bit mask of the offsets present in the tile; the main
+//    loop walks the set bits, so absent offsets cost nothing and no index load sits in the loop;
+//  - while the 16*NT MFMAs of offset k run, the gathered rows (4 x dwordx4 per lane) and the
+//    weight fragments (16*NT dwords per lane) of the NEXT present offset are already in flight
+//    into registers; they are written to LDS / consumed at the top of the next iteration.
+// Same arithmetic order as the simple form, hence the same bits.
+template <int NT>
+__global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma_pipe(
+    const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+    int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+    float* __restrict__ out) {
+  constexpr int CIN = 32;
+  constexpr int COUT = NT * 32;
+  constexpr int PITCH = CIN + 1;
+  __shared__ float a_lds[GC_WAVES][32 * PITCH];
+  __shared__ int32_t nb_lds[GC_WAVES][27 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
+  if (row0 >= n_out) return;  // wave-uniform
+  const int i = lane & 31, h = lane >> 5;
+  float* a = a_lds[wave];
+  int32_t* nbs = nb_lds[wave];
+
+  // ---- neighbour table of the tile + mask of present offsets
+  const bool row_ok = (row0 + i) < n_out;
+  uint32_t present = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    int32_t v = -1;
+    if (k < k_vol && row_ok) v = nbr[(int64_t)k * pitch + row0 + i];
+    if (h == 0) nbs[k * 32 + i] = v;
+    if (__ballot(v >= 0) != 0ull) present |= 1u << k;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float b = bias[t * 32 + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+  }
+
+  const int grow = lane >> 3, chunk = lane & 7;  // this lane gathers rows grow + 8*it, 16-B chunk `chunk`
+  float4 g[4];
+  float bw[NT][CIN / 2];
+
+  auto issue = [&](int k) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int32_t src = nbs[k * 32 + it * 8 + grow];
+      g[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src >= 0) g[it] = *reinterpret_cast<const float4*>(in + (int64_t)src * CIN + chunk * 4);
+    }
+    const float* wk = w + (int64_t)k * CIN * COUT;
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bw[t][s] = wk[(2 * s + h) * COUT + t * 32 + i];
+  };
+
+  uint32_t todo = present;
+  if (todo) issue(__builtin_ctz(todo));
+  while (todo) {
+    todo &= todo - 1;
+    // ---- land the prefetched rows in LDS, keep the weight fragments of this offset
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float* d = a + (it * 8 + grow) * PITCH + chunk * 4;
+      d[0] = g[it].x; d[1] = g[it].y; d[2] = g[it].z; d[3] = g[it].w;
+    }
+    float bc[NT][CIN / 2];
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bc[t][s] = bw[t][s];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- next present offset: rows and weights go in flight now
+    if (todo) issue(__builtin_ctz(todo));
+    // ---- contraction of the current offset
+    float av[CIN / 2];
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s) av[s] = a[i * PITCH + 2 * s + h];
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bc[t][s], acc[t], 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int64_t gr = row0 + row;
+      if (gr < n_out) {
+        float v = acc[t][r];
+        if (relu) v = fmaxf(v, 0.0f);
+        out[gr * COUT + t * 32 + i] = v;
+      }
+    }
+  }
+}
+
 // scalar-fmaf reference path on the GPU (any cin/cout), same bits as the MFMA path
 __global__ __launch_bounds__(256) void k_gconv_scalar(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
@@ -254,7 +367,14 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
   const unsigned gm = nblk(n_out, 32 * GC_WAVES);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
-  if (!force_scalar() && aligned && cin == 32 && cout == 32) {
+  static const bool simple = [] { const char* e = getenv("PCC_CONV_SIMPLE"); return e && e[0] == '1'; }();
+  if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32) {
+    hipLaunchKernelGGL((k_gconv_mfma_pipe<1>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
+                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+  } else if (!force_scalar() && !simple && aligned && cin == 32 && cout == 64) {
+    hipLaunchKernelGGL((k_gconv_mfma_pipe<2>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
+                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+  } else if (!force_scalar() && aligned && cin == 32 && cout == 32) {
     hipLaunchKernelGGL((k_gconv_mfma<32, 1>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
                        nbr_pitch, n_out, d_w, d_bias, relu, d_out);
   } else if (!force_scalar() && aligned && cin == 32 && cout == 64) {
