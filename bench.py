@@ -197,6 +197,19 @@ def main():
             ach = nbytes / avg_s / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
+        # same command, tools/pmc_summary.py); matched by kernel and grid size, else null
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            kname = {"sparse_conv": "k_gconv_mfma", "convT_gen": "k_convT_mfma"}[op]
+            grid = ((n_out + 127) // 128) * 256
+            for rec in pmc["kernels"]:
+                if kname in rec["kernel"] and rec["grid_threads"] == grid:
+                    roofline["traffic"] = rec["hbm_bytes_corrected"]
+                    roofline["traffic_source"] = "profiles/pmc_latest.json: (2*FETCH_SIZE+WRITE_SIZE)*1024"
+                    break
+        except (OSError, KeyError, ValueError):
+            pass
         roofline.update({"kernel": f"{op}{list(dims)}", "avg_ms": avg_s * 1e3, "launches": cnt,
                          "algorithmic_bytes": nbytes, "algorithmic_flops": flops, "active_pairs": p})
 

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "pcc_lookup": (i32, [vp, vp, i64, vp, i64, vp]),
     "pcc_gather_rows_or_zero": (i32, [vp, vp, vp, i64, i32, vp]),
     "pcc_sparse_conv": (i32, [vp, vp, i64, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp]),
+    "pcc_sparse_conv_head": (i32, [vp, vp, i64, vp, i32, i64, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "pcc_convT_gen": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "pcc_linear": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "pcc_topk_prune": (i32, [vp, vp, i64, i32, pi64, pi64, vp, pi64]),

@@ -121,17 +121,18 @@ class DecompressionPipeline:
                                           features=torch.ones((y_points.shape[0], 1)),
                                           tensor_stride=8, device=self.device)
         latent_coordinates.cs.set_batches(n_frames)
-        self._y_cs = latent_coordinates.cs
+        rt.y_latent = (y_points, latent_coordinates.cs)     # reused by the gaussian step of this call
         g_s = self.decompression_model.g_s
         latent_coordinates = g_s.down_conv(latent_coordinates)
         latent_coordinates = g_s.down_conv(latent_coordinates)
-        z_points = utils.sort_points(latent_coordinates.C)
+        z_view = utils.sort_coordset(latent_coordinates.cs)  # sort_points(latent_coordinates.C)
+        z_points = z_view.C
         if z_points.shape[0] != int(z_shapes):
             raise _rt.PccError(-5, "factorized_model_step_batched",
                                f"container says N_z={int(z_shapes)}, coordinates give {z_points.shape[0]}")
         eb = self.decompression_model.entropy_model.entropy_bottleneck
         z_hat_rows = eb.decompress_rows(rt, z_strings, int(z_shapes))
-        z_hat = SparseTensor(coordinates=z_points, features=z_hat_rows, tensor_stride=32, device=self.device)
+        z_hat = utils.sparse_from_rows(z_view, z_hat_rows)   # coordinates z_points, stride 32
         return z_hat, time.time() - t0
 
     def hyper_synthesis_step(self, z_hat):
@@ -146,7 +147,15 @@ class DecompressionPipeline:
         t0 = time.time()
         rt = _rt.current()
         em = self.decompression_model.entropy_model
-        y_points = utils.sort_points(y_points)
+        cached = getattr(rt, "y_latent", None)
+        if cached is not None and cached[0] is y_points:
+            y_cs = cached[1]                     # the coordinate set built from these points in step 3
+        else:
+            y_cs = SparseTensor(coordinates=y_points, features=torch.ones((y_points.shape[0], 1)),
+                                tensor_stride=8, device=self.device).cs
+        n_frames = y_cs.n_batch
+        y_view = utils.sort_coordset(y_cs)       # sort_points(y_points)
+        y_points = y_view.C
         if y_points.shape[0] != int(y_shapes):
             raise _rt.PccError(-5, "gaussian_model_step_batched",
                                f"container says N_y={int(y_shapes)}, geometry gives {y_points.shape[0]}")
@@ -156,8 +165,9 @@ class DecompressionPipeline:
         a, b = em.offsets_ab
         y_hat_rows = em.gaussian_conditional.decompress_rows(rt, y_strings[0], gaussian_params_feats, scale_dev,
                                                              a, b)
-        y_hat = SparseTensor(coordinates=y_points, features=y_hat_rows, tensor_stride=8, device=self.device)
-        y_hat.cs.set_batches(self._y_cs.n_batch)
+        y_hat = utils.sparse_from_rows(y_view, y_hat_rows)   # coordinates y_points, stride 8
+        y_hat.cs.set_batches(n_frames)
+        rt.y_latent = None
         return y_hat, time.time() - t0
 
     def hyper_synthesis(self, y_hat, ks):

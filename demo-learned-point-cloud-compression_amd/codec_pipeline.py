@@ -142,7 +142,7 @@ class CompressionPipeline:
         z_shapes = [int(zs.F.shape[0])]
         eb = self.compression_model.entropy_model.entropy_bottleneck
         z_strings, zhat_rows = eb.compress_rows(rt, zs.F)
-        z_hat = SparseTensor(coordinates=z_points, features=zhat_rows, tensor_stride=32, device=self.device)
+        z_hat = utils.sparse_from_rows(zs, zhat_rows)      # same coordinates as z, stride 32
         return z_hat, z_strings, z_shapes, z_points, time.time() - t0
 
     def hyper_synthesis_step(self, z_hat):

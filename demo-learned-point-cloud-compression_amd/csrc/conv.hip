@@ -120,11 +120,15 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma(
 //    weight fragments (16*NT dwords per lane) of the NEXT present offset are already in flight
 //    into registers; they are written to LDS / consumed at the top of the next iteration.
 // Same arithmetic order as the simple form, hence the same bits.
-template <int NT>
+// HEAD: additionally emits head_out[row] = head_b + sum_c fmaf(out[row][c], head_w[c]) (c ascending),
+// the 1x1 occupancy logit of g_s, from the tile while it is still on chip (saves re-reading the
+// whole feature tensor; same bits as pcc_linear on the stored output).
+template <int NT, bool HEAD>
 __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma_pipe(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
-    float* __restrict__ out) {
+    float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ head_out) {
   constexpr int CIN = 32;
   constexpr int COUT = NT * 32;
   constexpr int PITCH = CIN + 1;
@@ -216,11 +220,21 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma_pipe(
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
       const int64_t gr = row0 + row;
-      if (gr < n_out) {
-        float v = acc[t][r];
-        if (relu) v = fmaxf(v, 0.0f);
-        out[gr * COUT + t * 32 + i] = v;
-      }
+      float v = acc[t][r];
+      if (relu) v = fmaxf(v, 0.0f);
+      if (gr < n_out) out[gr * COUT + t * 32 + i] = v;
+      if constexpr (HEAD && NT == 1) a[row * PITCH + i] = v;  // the A tile buffer is free now
+    }
+  }
+  if constexpr (HEAD && NT == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 32 && row0 + lane < n_out) {
+      float hv = head_b[0];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) hv = fmaf(a[lane * PITCH + c], head_w[c], hv);
+      head_out[row0 + lane] = hv;
     }
   }
 }
@@ -341,6 +355,38 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ in, in
   out[t] = acc;
 }
 
+// 1x1 with coalesced row reads: a block stages 256 rows (cin*4 B each) through LDS with 16-B
+// lane loads, then thread t runs the fmaf chains of row t (pitch cin+1: conflict-free).  The
+// thread-per-row form above fetches every 128-B line up to 8 times (PMC: 2.2 GB for 0.42 GB of rows).
+template <int CIN>
+__global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ in, int64_t n,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int cout, int relu,
+                                                     float* __restrict__ out) {
+  constexpr int PITCH = CIN + 1;
+  constexpr int VEC = CIN / 4;  // float4 per row
+  __shared__ float tile[256 * PITCH];
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  for (int v = threadIdx.x; v < 256 * VEC; v += 256) {
+    const int r = v / VEC, c4 = v - r * VEC;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < n) x = *reinterpret_cast<const float4*>(in + (row0 + r) * CIN + c4 * 4);
+    float* d = tile + r * PITCH + c4 * 4;
+    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+  }
+  __syncthreads();
+  const int64_t row = row0 + threadIdx.x;
+  if (row >= n) return;
+  const float* x = tile + threadIdx.x * PITCH;
+  for (int co = 0; co < cout; ++co) {
+    float acc = bias[co];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc = fmaf(x[ci], w[ci * cout + co], acc);
+    if (relu) acc = fmaxf(acc, 0.0f);
+    out[row * cout + co] = acc;
+  }
+}
+
 // PCC_FORCE_SCALAR=1 in the environment routes every layer through the scalar
 // kernels (used by the parity tests to check MFMA == scalar on the device).
 static bool force_scalar() {
@@ -368,12 +414,14 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   const unsigned gm = nblk(n_out, 32 * GC_WAVES);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
   static const bool simple = [] { const char* e = getenv("PCC_CONV_SIMPLE"); return e && e[0] == '1'; }();
+  const float* nof = nullptr;
+  float* nofo = nullptr;
   if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32) {
-    hipLaunchKernelGGL((k_gconv_mfma_pipe<1>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
-                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+    hipLaunchKernelGGL((k_gconv_mfma_pipe<1, false>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr,
+                       k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);
   } else if (!force_scalar() && !simple && aligned && cin == 32 && cout == 64) {
-    hipLaunchKernelGGL((k_gconv_mfma_pipe<2>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
-                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+    hipLaunchKernelGGL((k_gconv_mfma_pipe<2, false>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr,
+                       k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);
   } else if (!force_scalar() && aligned && cin == 32 && cout == 32) {
     hipLaunchKernelGGL((k_gconv_mfma<32, 1>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
                        nbr_pitch, n_out, d_w, d_bias, relu, d_out);
@@ -389,6 +437,27 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   }
   PCC_CHECK_LAUNCH();
   return PCC_OK;
+}
+
+extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
+                                    int k_vol, int64_t nbr_pitch, int64_t n_out, const float* d_w,
+                                    const float* d_bias, int cin, int cout, int relu, float* d_out,
+                                    const float* d_head_w, const float* d_head_b, float* d_head_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv_head: null ctx");
+  PCC_REQUIRE(d_head_w && d_head_b && d_head_out, PCC_E_ARG, "pcc_sparse_conv_head: null head buffers");
+  const bool aligned = ((uintptr_t)d_in % 16 == 0);
+  if (n_out > 0 && !force_scalar() && aligned && cin == 32 && cout == 32 && (k_vol == 27 || k_vol == 8) &&
+      d_in && d_nbr && d_w && d_bias && d_out && nbr_pitch >= n_out && n_in > 0) {
+    PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
+    hipLaunchKernelGGL((k_gconv_mfma_pipe<1, true>), dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0,
+                       ctx->stream, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
+                       d_head_b, d_head_out);
+    PCC_CHECK_LAUNCH();
+    return PCC_OK;
+  }
+  // generic shapes: the two layers one after the other (same bits)
+  PCC_TRY(pcc_sparse_conv(ctx, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out));
+  return pcc_linear(ctx, d_out, n_out, d_head_w, d_head_b, cout, 1, 0, d_head_out);
 }
 
 extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, const float* d_w,
@@ -423,8 +492,13 @@ extern "C" int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const floa
   if (n <= 0) return PCC_OK;
   PCC_REQUIRE(d_in && d_w && d_bias && d_out, PCC_E_ARG, "pcc_linear: null buffers");
   PccProfScope prof(ctx, "linear", n, cin, cout, 1);
-  hipLaunchKernelGGL(k_linear, dim3(nblk(n * cout, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
-                     d_bias, cin, cout, relu, d_out);
+  if (!force_scalar() && cin == 32 && cout <= 8 && ((uintptr_t)d_in % 16 == 0)) {
+    hipLaunchKernelGGL((k_linear_rows<32>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
+                       d_bias, cout, relu, d_out);
+  } else {
+    hipLaunchKernelGGL(k_linear, dim3(nblk(n * cout, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
+                       d_bias, cin, cout, relu, d_out);
+  }
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

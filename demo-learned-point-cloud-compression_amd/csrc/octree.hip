@@ -48,6 +48,91 @@ __global__ void k_oct_leaves(const uint64_t* __restrict__ keys, int64_t n, int s
   if (i < n) leaves[i] = (keys[i] >> shift) & mask;
 }
 
+// ---- single-workgroup form (n <= OCT_SMALL_MAX): every level in one launch -----------------
+// Latent frames are ~1e3..3e4 leaves; the per-level launches above are pure launch latency for
+// them.  One 1024-thread block walks the levels bottom-up; per level it counts the parents
+// (block reduce), then scans tile by tile with a running carry and emits parents + occupancy
+// bytes.  Levels are packed back to front in `occ` so that the finished array is contiguous
+// root-first and ends at occ + cap.
+#define OCT_SMALL_MAX 65536
+#define OCT_T 1024
+
+__device__ __forceinline__ uint32_t oct_block_scan(uint32_t v, uint32_t* total, uint32_t* s_w) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < OCT_T / 64; ++w) {
+    const uint32_t s = s_w[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(OCT_T) void k_oct_small(const uint64_t* __restrict__ keys, int n, int shift,
+                                                     uint64_t mask, int depth, uint64_t* __restrict__ buf_a,
+                                                     uint64_t* __restrict__ buf_b, uint8_t* __restrict__ occ,
+                                                     int cap, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_w[OCT_T / 64];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < n; e += OCT_T) buf_a[e] = (keys[e] >> shift) & mask;
+  __threadfence_block();
+  __syncthreads();
+  uint64_t* cur = buf_a;
+  uint64_t* nxt = buf_b;
+  int n_cur = n, end = cap;
+  if (tid == 0) counts[depth] = (uint32_t)n;
+  for (int L = depth - 1; L >= 0; --L) {
+    // pass A: number of parents
+    uint32_t c = 0;
+    for (int e = tid; e < n_cur; e += OCT_T) c += (e == 0 || (cur[e - 1] >> 3) != (cur[e] >> 3)) ? 1u : 0u;
+    uint32_t m;
+    oct_block_scan(c, &m, s_w);
+    const int base_out = end - (int)m;
+    // pass B: scan tiles with a carry, emit
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < n_cur; t0 += OCT_T) {
+      const int e = t0 + tid;
+      uint32_t f = 0;
+      uint64_t pk = 0;
+      if (e < n_cur) {
+        pk = cur[e] >> 3;
+        f = (e == 0 || (cur[e - 1] >> 3) != pk) ? 1u : 0u;
+      }
+      uint32_t tile_tot;
+      const uint32_t ex = oct_block_scan(f, &tile_tot, s_w);
+      if (f) {
+        uint32_t byte = 0;
+        for (int j = e; j < n_cur && j < e + 8; ++j) {
+          const uint64_t k = cur[j];
+          if ((k >> 3) != pk) break;
+          byte |= 1u << (uint32_t)(k & 7ull);
+        }
+        const uint32_t p = carry + ex;
+        nxt[p] = pk;
+        occ[base_out + (int)p] = (uint8_t)byte;
+      }
+      carry += tile_tot;
+    }
+    if (tid == 0) counts[L] = m;
+    __threadfence_block();
+    __syncthreads();
+    uint64_t* t = cur; cur = nxt; nxt = t;
+    n_cur = (int)m;
+    end = base_out;
+  }
+}
+
 extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift,
                                  int depth, uint8_t* d_occ, int64_t cap, int64_t* h_level_n) {
   PCC_REQUIRE(ctx && h_level_n, PCC_E_ARG, "pcc_octree_levels: null arg");
@@ -68,6 +153,30 @@ extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n
   if (!buf_a || !buf_b || !flags || !excl || !occ_lv || !counts) return PCC_E_NOMEM;
   const size_t mark = ctx->arena_off;
   PccProfScope prof(ctx, "octree_levels", n, depth, 0, 0);
+  const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
+
+  if (n <= OCT_SMALL_MAX) {
+    // one launch; levels packed back to front in occ_lv[0 .. depth*n1), one read-back, one copy
+    const int cap_s = (int)((size_t)depth * n1);
+    hipLaunchKernelGGL(k_oct_small, dim3(1), dim3(OCT_T), 0, st, d_keys, (int)n, key_shift, leaf_mask, depth,
+                       buf_a, buf_b, occ_lv, cap_s, counts);
+    PCC_CHECK_LAUNCH();
+    uint32_t* hc = (uint32_t*)ctx->pinned;
+    PCC_HIP(hipMemcpyAsync(hc, counts, (size_t)(depth + 1) * 4, hipMemcpyDeviceToHost, st));
+    PCC_HIP(hipStreamSynchronize(st));
+    int64_t tot = 0;
+    for (int L = 0; L < depth; ++L) {
+      h_level_n[L] = (int64_t)hc[L];
+      tot += h_level_n[L];
+    }
+    PCC_REQUIRE(h_level_n[0] == 1, PCC_E_ARG,
+                "pcc_octree_levels: keys exceed 3*depth bits (root level has %lld nodes)",
+                (long long)h_level_n[0]);
+    PCC_REQUIRE(tot <= cap, PCC_E_ARG, "pcc_octree_levels: d_occ capacity %lld < %lld", (long long)cap,
+                (long long)tot);
+    PCC_HIP(hipMemcpyAsync(d_occ, occ_lv + (cap_s - tot), (size_t)tot, hipMemcpyDeviceToDevice, st));
+    return PCC_OK;
+  }
 
   hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + depth, (uint32_t)n);
   PCC_CHECK_LAUNCH();

@@ -38,6 +38,27 @@ constexpr uint32_t kBypassBits = 4;
 constexpr uint32_t kMaxBypass = (1u << kBypassBits) - 1;  // 15
 constexpr uint64_t kRansL = 1ull << 31;
 
+// Exact x / d for every 64-bit x and 1 <= d <= 65536 without a divide instruction
+// (Granlund & Montgomery, "Division by invariant integers using multiplication", fig. 4.1,
+// N = 64): l = ceil(log2 d), m = floor(2^64 (2^l - d) / d) + 1,
+// q = (t + ((x - t) >> min(l,1))) >> max(l-1,0) with t = mulhi(m, x).
+struct Rcp {
+  uint64_t m;
+  uint8_t sh1, sh2;
+};
+static Rcp g_rcp[65537];
+static const bool g_rcp_init = [] {
+  for (uint32_t d = 1; d <= 65536; ++d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned __int128 num = (unsigned __int128)((1ull << l) - d) << 64;
+    g_rcp[d].m = (uint64_t)(num / d) + 1;
+    g_rcp[d].sh1 = (uint8_t)(l < 1 ? l : 1);
+    g_rcp[d].sh2 = (uint8_t)(l > 0 ? l - 1 : 0);
+  }
+  return true;
+}();
+
 struct Enc {
   uint64_t x;
   uint32_t* ptr;    // next word is written at --ptr
@@ -51,7 +72,10 @@ struct Enc {
   inline void put(uint32_t start, uint32_t freq) {
     const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
     if (x >= x_max) { emit((uint32_t)x); x >>= 32; }
-    x = ((x / freq) << kPrecision) + (x % freq) + start;
+    const Rcp& r = g_rcp[freq];
+    const uint64_t t = (uint64_t)(((unsigned __int128)r.m * x) >> 64);
+    const uint64_t q = (t + ((x - t) >> r.sh1)) >> r.sh2;   // == x / freq
+    x = (q << kPrecision) + (x - q * freq) + start;
   }
   inline void put_bits(uint32_t val) {
     const uint32_t freq = 1u << (16 - kBypassBits);

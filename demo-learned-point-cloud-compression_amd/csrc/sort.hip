@@ -150,6 +150,117 @@ static size_t sort_scratch_bytes(int64_t n) {
          pcc_align((size_t)256 * nw * 4) + pcc_scan_scratch_bytes(256 * nw) + 1024;
 }
 
+// ---- single-workgroup sort for the latent-sized tensors (n <= SS_MAX) ----------------------
+// The y / z tensors are 1e3..3e4 rows; the multi-kernel path above costs ~30 launches and a
+// host read-back for them.  Here one 1024-thread block runs every pass: each of its 16 waves
+// owns a contiguous chunk (stable order = wave-major), counts its digits into its LDS row,
+// thread d turns the 16x256 counts into exclusive offsets, and each wave scatters its chunk with
+// the same match-ballot ranking as k_radix_scatter.  Constant digits are detected in the kernel
+// and skipped; the result always ends in (keys, perm), so no host synchronisation is needed.
+#define SS_THREADS 1024
+#define SS_WAVES (SS_THREADS / 64)
+#define SS_MAX 65536
+
+__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ perm,
+                                                           uint64_t* __restrict__ tmp_k,
+                                                           uint32_t* __restrict__ tmp_v, int n, uint64_t flip) {
+  __shared__ uint32_t cnt[SS_WAVES][256];
+  __shared__ unsigned long long s_or, s_and;
+  __shared__ uint32_t s_wsum[SS_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = ((n + SS_WAVES - 1) / SS_WAVES + 63) & ~63;  // elements per wave, multiple of 64
+  const int c0 = wave * chunk, c1 = min(n, c0 + chunk);
+  const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  // which digits vary at all?
+  if (tid == 0) { s_or = 0ull; s_and = ~0ull; }
+  __syncthreads();
+  {
+    uint64_t o = 0, a = ~0ull;
+    for (int e = tid; e < n; e += SS_THREADS) { const uint64_t k = keys[e]; o |= k; a &= k; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      o |= __shfl_xor((unsigned long long)o, d, 64);
+      a &= __shfl_xor((unsigned long long)a, d, 64);
+    }
+    if (lane == 0) { atomicOr(&s_or, (unsigned long long)o); atomicAnd(&s_and, (unsigned long long)a); }
+  }
+  __syncthreads();
+  const uint64_t varying = s_or & ~s_and;
+
+  uint64_t* kin = keys;
+  uint64_t* kout = tmp_k;
+  uint32_t* vin = nullptr;  // identity on the first executed pass
+  uint32_t* vout = tmp_v;
+  for (int p = 0; p < 8; ++p) {
+    if (((varying >> (8 * p)) & 0xFFull) == 0) continue;  // block-uniform
+    const int shift = 8 * p;
+    // (a) per-wave digit counts
+    for (int d = lane; d < 256; d += 64) cnt[wave][d] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = c0 + lane; e < c1; e += 64) atomicAdd(&cnt[wave][(uint32_t)(((kin[e] ^ flip) >> shift) & 255u)], 1u);
+    __syncthreads();
+    // (b) counts -> exclusive offsets: digit-major, wave-minor
+    uint32_t tot = 0;
+    if (tid < 256) {
+      for (int w = 0; w < SS_WAVES; ++w) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = tot; tot += c; }
+    }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t base = inc - tot;
+      for (int w = 0; w < wave; ++w) base += s_wsum[w];
+      for (int w = 0; w < SS_WAVES; ++w) cnt[w][tid] += base;
+    }
+    __syncthreads();
+    // (c) stable scatter of this wave's chunk
+    volatile uint32_t* base = cnt[wave];
+    for (int e0 = c0; e0 < c1; e0 += 64) {
+      const int e = e0 + lane;
+      const bool valid = e < c1;
+      uint64_t key = 0;
+      uint32_t val = 0;
+      if (valid) { key = kin[e]; val = vin ? vin[e] : (uint32_t)e; }
+      const uint32_t d = (uint32_t)(((key ^ flip) >> shift) & 255u);
+      uint64_t mask = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+      }
+      const uint32_t rank = (uint32_t)__popcll(mask & lanes_below);
+      const uint32_t c = (uint32_t)__popcll(mask);
+      uint32_t pos = 0;
+      if (valid) pos = base[d] + rank;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && rank == 0) base[d] = pos + c;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) { kout[pos] = key; vout[pos] = val; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* nv = (vout == tmp_v) ? perm : tmp_v;
+    vin = vout;
+    vout = nv;
+  }
+  // land the result in (keys, perm)
+  if (vin == nullptr) {
+    for (int e = tid; e < n; e += SS_THREADS) perm[e] = (uint32_t)e;
+  } else {
+    if (kin != keys) for (int e = tid; e < n; e += SS_THREADS) keys[e] = kin[e];
+    if (vin != perm) for (int e = tid; e < n; e += SS_THREADS) perm[e] = vin[e];
+  }
+}
+
 // Sort with scratch already reserved in the arena.
 static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
                            int is_signed) {
@@ -163,6 +274,13 @@ static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int
   const int64_t nw = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
   uint64_t* tmp_k = (uint64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
   uint32_t* tmp_v = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
+  if (n <= SS_MAX) {
+    if (!tmp_k || !tmp_v) return PCC_E_NOMEM;
+    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, st, d_keys, d_perm, tmp_k, tmp_v, (int)n,
+                       is_signed ? (1ull << 63) : 0ull);
+    PCC_CHECK_LAUNCH();
+    return PCC_OK;
+  }
   uint32_t* counts = (uint32_t*)pcc_arena_alloc(ctx, (size_t)256 * nw * 4);
   unsigned long long* orand = (unsigned long long*)pcc_arena_alloc(ctx, 16);
   if (!tmp_k || !tmp_v || !counts || !orand) return PCC_E_NOMEM;

@@ -112,8 +112,11 @@ class SynthesisTransform:
         _ = h.cs.offsets
         for j in range(3):
             h = up2(p, f"g_s.up{j}", h, True)
-            h = conv3(p, f"g_s.conv{j}", h, True)
-            logits = linear(p, f"g_s.occ{j}", h)
+            # conv3 + ReLU with the 1x1 occupancy head fused into its epilogue
+            w, b = p.wb(f"g_s.conv{j}")
+            hw, hb = p.wb(f"g_s.occ{j}")
+            feats, logits = h.rt.sparse_conv_head(h.F, h.cs.nbr27(), w, b, True, hw, hb)
+            h = SparseTensor(feats, coordset=h.cs)
             offs = h.cs.offsets
             kj = [min(int(k[j][f]), offs[f + 1] - offs[f]) for f in range(n_batch)]
             keep = h.rt.topk_prune(logits.view(-1), offs, kj)

@@ -255,6 +255,18 @@ class Runtime:
               "pcc_sparse_conv")
         return out
 
+    def sparse_conv_head(self, x, nbr, w, b, relu, head_w, head_b):
+        """conv layer + fused 1x1 head (cout -> 1): returns (features [n,cout], logits [n])"""
+        k_vol, n_out = nbr.shape
+        cin, cout = w.shape[1], w.shape[2]
+        assert x.shape[1] == cin and w.shape[0] == k_vol and head_w.numel() == cout
+        out = self.empty((n_out, cout), torch.float32)
+        logits = self.empty((n_out,), torch.float32)
+        check(self.lib.pcc_sparse_conv_head(self.ctx, _ptr(x), x.shape[0], _ptr(nbr), k_vol, nbr.stride(0), n_out,
+                                            _ptr(w), _ptr(b), cin, cout, 1 if relu else 0, _ptr(out),
+                                            _ptr(head_w), _ptr(head_b), _ptr(logits)), "pcc_sparse_conv_head")
+        return out, logits
+
     def convT_gen(self, x, w, b, relu):
         n, cin, cout = x.shape[0], w.shape[1], w.shape[2]
         assert x.shape[1] == cin and w.shape[0] == 8

@@ -35,11 +35,30 @@ def stack_tensors(points, colors=None):
 class RowView:
     """coordinates / features of a sparse tensor in canonical order"""
 
-    def __init__(self, coords, feats, stride, perm=None):
+    def __init__(self, coords, feats, stride, perm=None, cs=None):
         self.C = coords
         self.F = feats
         self.tensor_stride = [stride] * 3
-        self.perm = perm
+        self.perm = perm          # canonical position -> row of the underlying (Morton-ordered) tensor
+        self.cs = cs              # CoordSet of the underlying tensor
+
+
+def sort_coordset(cs):
+    """canonical-order view of a coordinate set (no features)"""
+    rt = cs.rt
+    coords = cs.C
+    perm = rt.sort_coords(coords)
+    return RowView(rt.gather_rows(coords, perm), None, cs.stride, perm, cs)
+
+
+def sparse_from_rows(view, feats):
+    """SparseTensor on the coordinates of `view` from features given in the view's canonical
+    row order — what the reference gets by re-constructing ME.SparseTensor(coordinates=sorted C,
+    features=...) (codec_pipeline.py:308-313, codec_parallel.py:309-314,411-416), without
+    re-inserting the same coordinates."""
+    rt = view.cs.rt
+    inv = rt.inverse_rows(view.perm, view.perm.shape[0])
+    return SparseTensor(rt.gather_rows(feats, inv), coordset=view.cs)
 
 
 def sort_points(points):
@@ -59,7 +78,7 @@ def sort_tensor(sparse_tensor):
     coords = sparse_tensor.C
     perm = rt.sort_coords(coords)
     feats = rt.gather_rows(sparse_tensor.F, perm) if sparse_tensor.F is not None else None
-    return RowView(rt.gather_rows(coords, perm), feats, sparse_tensor.cs.stride, perm)
+    return RowView(rt.gather_rows(coords, perm), feats, sparse_tensor.cs.stride, perm, sparse_tensor.cs)
 
 
 def _split_offsets(coords_host):

@@ -191,6 +191,15 @@ int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                     const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
                     int64_t n_out, const float* d_w, const float* d_bias,
                     int cin, int cout, int relu, float* d_out);
+/* the same layer with the 1x1 occupancy head of g_s fused into its epilogue:
+ * d_head_out[n] = head_b[0] + sum_c fmaf(out[n][c], head_w[c]) (c ascending) —
+ * bit-identical to pcc_linear(cout -> 1) applied to d_out, without re-reading it. */
+int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in,
+                         const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
+                         int64_t n_out, const float* d_w, const float* d_bias,
+                         int cin, int cout, int relu, float* d_out,
+                         const float* d_head_w, const float* d_head_b,
+                         float* d_head_out);
 /* replaces: MinkowskiGenerativeConvolutionTranspose forward (kernel 2,
  * stride 2): out[8p+o] = W[o]^T in[p] + bias. */
 int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in,

@@ -226,6 +226,24 @@ def test_conv_linearity(rt, oracle, clouds):
     assert np.array_equal(o1 * 4, o2)
 
 
+@pytest.mark.parametrize("name", ["surf", "tiny", "one"])
+@pytest.mark.parametrize("cin", [32, 4])
+def test_sparse_conv_fused_head_bit_exact(rt, oracle, clouds, name, cin):
+    """conv3 + ReLU with the 1x1 occupancy head in its epilogue == the two layers of the oracle"""
+    rng = np.random.default_rng(77)
+    keys = sorted_keys(oracle, clouds[name])
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(len(keys), cin)).astype(np.float32)
+    w, b = _weights(rng, 27, cin, 32)
+    hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
+    hb = rng.normal(0, 0.1, 1).astype(np.float32)
+    feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw),
+                                        dev(rt, hb))
+    ref = oracle.sparse_conv(x, nbr, w, b, True)
+    assert np.array_equal(host(feats), ref)
+    assert np.array_equal(host(logits), oracle.linear(ref, hw, hb)[:, 0])
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (5, 3)])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 700])
 def test_convT_gen_bit_exact(rt, oracle, cin, cout, n):
