@@ -87,11 +87,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # one rank per GPU; PCC_BENCH_BACKEND=gloo lets several ranks share a GPU (used only to rehearse
+    # the multi-rank control flow on a one-GPU box — RCCL refuses two ranks on one device)
+    backend = os.environ.get("PCC_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module(PKG)
     wl = importlib.import_module(PKG + ".workloads")
@@ -136,7 +143,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
