@@ -5,6 +5,7 @@
 the reference's sideinfo keys (including the spelling "guassian_model") and
 stage taxonomy D1..D6.  All stage work runs in libpcc_hip.so on the MI355X.
 """
+import concurrent.futures
 import queue
 import struct
 import time
@@ -28,6 +29,7 @@ class DecompressionPipeline:
         self.runtimes = [_rt.Runtime(device) for _ in range(slots)]
         for r in self.runtimes:
             self._slots.put(r)
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, slots))
 
     def load_model(self, base_path):
         model_name = "demo_small"
@@ -47,8 +49,12 @@ class DecompressionPipeline:
             with rt:
                 y_strings, z_strings, y_shapes, z_shapes, points_streams, ks, q, t_1 = \
                     self.read_bitstream_batched(compressed_data)
+                # the z string needs nothing from the GPU: decode it on the helper thread while the
+                # geometry is decoded and the z coordinates are re-derived on the device
+                eb = self.decompression_model.entropy_model.entropy_bottleneck
+                z_sym = self._pool.submit(eb.decode_host, z_strings, int(z_shapes))
                 y_points, t_2 = self.geometry_decompression_step(points_streams)
-                z_hats, t_3 = self.factorized_model_step_batched(z_strings, z_shapes, y_points)
+                z_hats, t_3 = self.factorized_model_step_batched(z_strings, z_shapes, y_points, z_sym=z_sym)
                 gaussian_params, t_4 = self.hyper_synthesis_step(z_hats)
                 y_hat, t_5 = self.gaussian_model_step_batched(y_strings, y_shapes, y_points, q, gaussian_params)
                 reconstructed_pointcloud, t_6 = self.hyper_synthesis(y_hat, ks)
@@ -111,7 +117,7 @@ class DecompressionPipeline:
         y_points = utils.stack_tensors(y_points)
         return y_points, time.time() - t0
 
-    def factorized_model_step_batched(self, z_strings, z_shapes, y_points):
+    def factorized_model_step_batched(self, z_strings, z_shapes, y_points, z_sym=None):
         """Step 3: re-derive the z coordinates from the y coordinates with two
         stride-2 maps, decode z (codec_parallel.py:291-318)"""
         t0 = time.time()
@@ -131,7 +137,8 @@ class DecompressionPipeline:
             raise _rt.PccError(-5, "factorized_model_step_batched",
                                f"container says N_z={int(z_shapes)}, coordinates give {z_points.shape[0]}")
         eb = self.decompression_model.entropy_model.entropy_bottleneck
-        z_hat_rows = eb.decompress_rows(rt, z_strings, int(z_shapes))
+        z_hat_rows = eb.decompress_rows(rt, z_strings, int(z_shapes),
+                                        sym=z_sym.result() if z_sym is not None else None)
         z_hat = utils.sparse_from_rows(z_view, z_hat_rows)   # coordinates z_points, stride 32
         return z_hat, time.time() - t0
 

@@ -13,6 +13,7 @@ sharing one results queue — the reference's hand-off can return another
 caller's GOP when `compress` is called concurrently; the
 geometry slot holds this build's octree blob instead of a tmc3 stream.
 """
+import concurrent.futures
 import queue
 import struct
 import time
@@ -41,6 +42,15 @@ class CompressionPipeline:
         scale = np.concatenate([em.scale_nn(np.asarray([q], dtype=np.float32)) + em.eps for q in self.settings], 0)
         self._scale_host = np.ascontiguousarray(scale, dtype=np.float32)
         self._scale_dev = torch.from_numpy(self._scale_host).to(self.device)
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, slots))
+
+    @staticmethod
+    def _after(event, job):
+        """helper-thread body: wait until the stream has produced the job's inputs, then run it"""
+        event.synchronize()
+        t0 = time.time()
+        out = job()
+        return out, time.time() - t0
 
     def load_model(self, base_path):
         model_name = "demo_small"
@@ -62,12 +72,25 @@ class CompressionPipeline:
             with rt:
                 pointclouds, sideinfo = self.unpack_batch(data)
                 y, k, y_points, t_1 = self.analysis_step(pointclouds)
-                points_streams, t_5 = self.geometry_compression_step(y_points)
+                # The host halves of the geometry slot and of the z stream do not feed the GPU
+                # path (z_hat is formed on the device), so they run on the helper thread while
+                # the GPU continues with h_a / h_s / the y symbols — the overlap the reference
+                # gets from its stage threads (codec_pipeline.py:90-92: geometry || hyper path).
+                geom_job, t_5a = self.geometry_compression_step(y_points, defer=True)
+                ev_g = torch.cuda.Event()
+                ev_g.record(rt.stream)
+                geom_future = self._pool.submit(self._after, ev_g, geom_job)
                 z, t_2 = self.hyper_analysis_step(y)
-                z_hat, z_strings, z_shapes, z_points, t_3 = self.factorized_model_step_batched(z)
+                z_hat, z_job, z_shapes, z_points, t_3 = self.factorized_model_step_batched(z, defer=True)
+                ev_z = torch.cuda.Event()
+                ev_z.record(rt.stream)
+                z_future = self._pool.submit(self._after, ev_z, z_job)
                 gaussian_params, t_4 = self.hyper_synthesis_step(z_hat)
                 y_strings, y_shapes, t_6 = self.gaussian_model_step_batched(y, y_points, self.settings,
                                                                             gaussian_params)
+                points_streams, t_5b = geom_future.result()
+                z_strings, t_3b = z_future.result()
+                t_5, t_3 = t_5a + t_5b, t_3 + t_3b
                 t_7s = []
                 for i, q in enumerate(self.settings):
                     byte_array, t_7 = self.make_bitstream_batched(y_strings[i], z_strings, y_shapes, z_shapes,
@@ -131,17 +154,18 @@ class CompressionPipeline:
         z.rt.sync()
         return z, time.time() - t0
 
-    def factorized_model_step_batched(self, z):
+    def factorized_model_step_batched(self, z, defer=False):
         """Step 3: factorized entropy model over the canonically sorted z
         (one rANS stream over [1, C_z, N_z]); returns z_hat like the reference,
-        which decodes its own string to get it (codec_pipeline.py:294-317)."""
+        which decodes its own string to get it (codec_pipeline.py:294-317).
+        defer=True: `z_strings` is returned as a function doing the host rANS."""
         t0 = time.time()
         rt = z.rt
         zs = utils.sort_tensor(z)
         z_points = zs.C
         z_shapes = [int(zs.F.shape[0])]
         eb = self.compression_model.entropy_model.entropy_bottleneck
-        z_strings, zhat_rows = eb.compress_rows(rt, zs.F)
+        z_strings, zhat_rows = eb.compress_rows(rt, zs.F, defer=defer)
         z_hat = utils.sparse_from_rows(zs, zhat_rows)      # same coordinates as z, stride 32
         return z_hat, z_strings, z_shapes, z_points, time.time() - t0
 
@@ -163,15 +187,22 @@ class CompressionPipeline:
         shapes = [int(ys.F.shape[0])]
         return y_strings, shapes, time.time() - t0
 
-    def geometry_compression_step(self, y_points):
+    def geometry_compression_step(self, y_points, defer=False):
         """Step 6: lossless coding of the latent coordinates, one blob per frame
-        (codec_pipeline.py:441-462; tmc3 in the reference)."""
+        (codec_pipeline.py:441-462; tmc3 in the reference).  The octree occupancy bytes are
+        built on the GPU here; defer=True returns the host entropy coding as a function."""
         t0 = time.time()
         offs = y_points["offsets"]
-        point_bitstreams = []
-        for f in range(len(offs) - 1):
-            point_bitstreams.append(utils.gpcc_encode(y_points["keys"], y_points["keys_host"], offs[f],
-                                                      offs[f + 1], 9))
+        jobs = [utils.gpcc_encode_begin(y_points["keys"], y_points["keys_host"], offs[f], offs[f + 1], 9, slot=f)
+                for f in range(len(offs) - 1)]
+
+        def finish():
+            return [job() for job in jobs]
+
+        if defer:
+            return finish, time.time() - t0
+        _rt.current().sync()
+        point_bitstreams = finish()
         return point_bitstreams, time.time() - t0
 
     def make_bitstream_batched(self, y_string, z_string, y_shape, z_shape, points_streams, ks, q):

@@ -189,6 +189,18 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
   __syncthreads();
   const uint64_t varying = s_or & ~s_and;
 
+  // already sorted (e.g. coordinates that come out of the octree decoder in Morton order):
+  // identity permutation, no pass at all
+  {
+    bool ok = true;
+    for (int e = tid + 1; e < n; e += SS_THREADS) ok &= (keys[e - 1] ^ flip) <= (keys[e] ^ flip);
+    const bool all_ok = __syncthreads_and(ok);
+    if (all_ok) {
+      for (int e = tid; e < n; e += SS_THREADS) perm[e] = (uint32_t)e;
+      return;
+    }
+  }
+
   uint64_t* kin = keys;
   uint64_t* kout = tmp_k;
   uint32_t* vin = nullptr;  // identity on the first executed pass

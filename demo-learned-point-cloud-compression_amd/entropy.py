@@ -49,15 +49,29 @@ class EntropyBottleneck:
         return np.repeat(np.arange(self.channels, dtype=np.int32), n)
 
     # fused form used by the pipeline: z rows [N,C] in coding order
-    def compress_rows(self, rt, z_rows):
+    def compress_rows(self, rt, z_rows, defer=False):
+        """returns (strings, z_hat rows).  With defer=True `strings` is a zero-argument function
+        doing the host rANS (to be called once the stream has passed this point): z_hat is formed
+        on the device and does not depend on the byte string."""
         sym, zhat = rt.factorized_quant(z_rows, self.medians)
         n = z_rows.shape[0]
-        sym_h = sym.cpu().numpy().reshape(1, -1)
-        strings = self.coder.encode(sym_h, self._indexes(n).reshape(1, -1))
-        return strings, zhat
+        sym_h = rt.to_host_async(sym, "z_sym")
 
-    def decompress_rows(self, rt, strings, n):
-        sym = self.coder.decode(strings[0], self._indexes(n))
+        def finish():
+            return self.coder.encode(sym_h.reshape(1, -1), self._indexes(n).reshape(1, -1))
+
+        if defer:
+            return finish, zhat
+        rt.sync()
+        return finish(), zhat
+
+    def decode_host(self, strings, n):
+        """host half of decompress: rANS decode of the z string -> int32 [C*n] (no GPU involved)"""
+        return self.coder.decode(strings[0], self._indexes(n))
+
+    def decompress_rows(self, rt, strings, n, sym=None):
+        if sym is None:
+            sym = self.decode_host(strings, n)
         sym_d = rt.to_device(sym.reshape(self.channels, n), torch.int32)
         return rt.factorized_dequant(sym_d, self.medians)
 

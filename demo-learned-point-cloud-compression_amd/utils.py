@@ -132,6 +132,22 @@ def octree_depth_origin(first_key, last_key, key_shift):
     return depth, origin
 
 
+def gpcc_encode_begin(keys_dev, keys_host, lo, hi, key_shift, slot=0):
+    """Device half of gpcc_encode: octree occupancy bytes of rows [lo,hi) on the GPU and an
+    asynchronous copy into a pinned buffer.  Returns a zero-argument function that does the host
+    half (entropy coding) and returns the blob; call it after the stream has reached this point
+    (it is what CompressionPipeline runs on its helper thread while the GPU continues with h_a/h_s)."""
+    rt = _rt.current()
+    n = hi - lo
+    if n == 0:
+        return lambda: _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
+    first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
+    depth, origin = octree_depth_origin(first, last, key_shift)
+    occ, level_n = rt.octree_levels(keys_dev[lo:hi], key_shift, depth)
+    occ_h = rt.to_host_async(occ, f"occ{slot}")
+    return lambda: _rt.octree_pack(occ_h, level_n, n, origin)
+
+
 def gpcc_encode(keys_dev, keys_host, lo, hi, key_shift):
     """Lossless geometry blob for rows [lo,hi) of a Morton-sorted key array.
     Stands in for utils.gpcc_encode (shared/utils.py:169-207): the reference
