@@ -64,6 +64,8 @@ PROTOTYPES = {
     "pcc_factorized_dequant": (i32, [vp, vp, i64, i32, vp, vp]),
     "pcc_gaussian_quant": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "pcc_gaussian_indexes": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
+    "pcc_build_indexes": (i32, [vp, vp, i64, vp, i32, vp]),
+    "pcc_quantize_symbols": (i32, [vp, vp, vp, i64, vp]),
     "pcc_gaussian_quant16": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, vp]),
     "pcc_gaussian_indexes8": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
     "pcc_rans_encode_multi16": (i32, [vp, vp, i64, i32, vp, i32, vp, vp, i32, vp, i64, pi64]),

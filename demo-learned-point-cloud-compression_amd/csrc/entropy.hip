@@ -148,6 +148,47 @@ __global__ __launch_bounds__(256) void k_gaussian_dequant(const int32_t* __restr
   yhat[i * c + ch] = __fadd_rn(__fmul_rn(v, rescale), mu);
 }
 
+// ---- element-wise forms behind the CompressAI-shaped methods (any tensor shape, flat) --------
+__global__ __launch_bounds__(256) void k_build_indexes(const float* __restrict__ scales, int64_t n,
+                                                       const float* __restrict__ table, int n_tab,
+                                                       int32_t* __restrict__ idx) {
+  __shared__ float tab[64];
+  if (threadIdx.x < n_tab) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) idx[t] = scale_index(scales[t], tab, n_tab);
+}
+
+__global__ __launch_bounds__(256) void k_quantize_symbols(const float* __restrict__ x,
+                                                          const float* __restrict__ means /*nullable*/,
+                                                          int64_t n, int32_t* __restrict__ sym) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float v = means ? __fsub_rn(x[t], means[t]) : x[t];
+  sym[t] = (int32_t)rintf(v);
+}
+
+extern "C" int pcc_build_indexes(pcc_ctx* ctx, const float* d_scales, int64_t n, const float* d_table,
+                                 int n_tab, int32_t* d_idx) {
+  PCC_REQUIRE(ctx && n_tab >= 2 && n_tab <= 64, PCC_E_ARG, "pcc_build_indexes: bad arg");
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_scales && d_table && d_idx, PCC_E_ARG, "pcc_build_indexes: null buffers");
+  hipLaunchKernelGGL(k_build_indexes, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_scales, n, d_table,
+                     n_tab, d_idx);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_quantize_symbols(pcc_ctx* ctx, const float* d_x, const float* d_means, int64_t n,
+                                    int32_t* d_sym) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_quantize_symbols: null ctx");
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_x && d_sym, PCC_E_ARG, "pcc_quantize_symbols: null buffers");
+  hipLaunchKernelGGL(k_quantize_symbols, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_x, d_means, n, d_sym);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 extern "C" int pcc_factorized_quant(pcc_ctx* ctx, const float* d_z, int64_t n, int c,
                                     const float* d_med, int32_t* d_sym, float* d_zhat) {
   PCC_REQUIRE(ctx && c >= 1, PCC_E_ARG, "pcc_factorized_quant: bad arg");

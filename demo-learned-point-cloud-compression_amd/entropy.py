@@ -79,7 +79,7 @@ class EntropyBottleneck:
     def compress(self, x):
         rt = _rt.current()
         assert x.dim() == 3 and x.shape[0] == 1
-        rows = x[0].t().contiguous()
+        rows = rt.to_device(x[0].t().contiguous(), torch.float32)
         strings, _ = self.compress_rows(rt, rows)
         return strings
 
@@ -102,6 +102,31 @@ class GaussianConditional:
 
     def lower_bound_scale(self, scales):
         return torch.clamp(scales, min=float(self.scale_bound))
+
+    # CompressAI-shaped surface ([B, C, N] tensors), as the reference calls it --------------
+    def build_indexes(self, scales):
+        """codec_pipeline.py:425 / codec_parallel.py:398: int32 tensor of the same shape"""
+        rt = _rt.current()
+        return rt.build_indexes(rt.to_device(scales, torch.float32), self.scale_table)
+
+    def compress(self, inputs, indexes, means=None):
+        """codec_pipeline.py:426-430: one rANS string per batch item over the flattened [C, N]"""
+        rt = _rt.current()
+        inputs = rt.to_device(inputs, torch.float32)
+        means = rt.to_device(means, torch.float32) if means is not None else None
+        sym = rt.quantize_symbols(inputs, means)
+        b = sym.shape[0]
+        sym_h = sym.cpu().numpy().reshape(b, -1)
+        idx_h = indexes.cpu().numpy().astype(np.int32, copy=False).reshape(b, -1)
+        return self.coder.encode(sym_h, idx_h)
+
+    def decompress(self, strings, indexes):
+        """codec_parallel.py:400: no means -> the raw integer residuals as floats, shape of `indexes`"""
+        idx_h = indexes.cpu().numpy().astype(np.int32, copy=False)
+        b = idx_h.shape[0]
+        out = np.stack([self.coder.decode(strings[i], idx_h[i].reshape(-1)) for i in range(b)], 0)
+        rt = _rt.current()
+        return rt.to_device(out.reshape(idx_h.shape).astype(np.float32))
 
     # fused forms used by the pipeline ------------------------------------
     def compress_rows(self, rt, y_rows, params_rows, scale_q):

@@ -34,7 +34,15 @@ def current():
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+    """device pointer of a tensor (NULL for None / empty).  A host tensor here would make a kernel
+    dereference a host address — refuse it before it reaches the GPU."""
+    if t is None or t.numel() == 0:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise TypeError("device tensor expected, got a host tensor")
+    if not t.is_contiguous():
+        raise TypeError("contiguous device tensor expected")
+    return C.c_void_p(t.data_ptr())
 
 
 def _np_ptr(a):
@@ -317,6 +325,23 @@ class Runtime:
         check(self.lib.pcc_gaussian_quant(self.ctx, _ptr(y), _ptr(params), n, c, _ptr(scale), q, _ptr(table),
                                           table.shape[0], _ptr(sym), _ptr(idx)), "pcc_gaussian_quant")
         return sym, idx
+
+    def build_indexes(self, scales, table):
+        """element-wise GaussianConditional.build_indexes on a tensor of any shape"""
+        scales = scales.contiguous()
+        idx = self.empty(tuple(scales.shape), torch.int32)
+        check(self.lib.pcc_build_indexes(self.ctx, _ptr(scales), scales.numel(), _ptr(table), table.shape[0],
+                                         _ptr(idx)), "pcc_build_indexes")
+        return idx
+
+    def quantize_symbols(self, x, means=None):
+        """element-wise round(x - means) -> int32 (EntropyModel.quantize(..., "symbols", means))"""
+        x = x.contiguous()
+        means = means.contiguous() if means is not None else None
+        sym = self.empty(tuple(x.shape), torch.int32)
+        check(self.lib.pcc_quantize_symbols(self.ctx, _ptr(x), _ptr(means), x.numel(), _ptr(sym)),
+              "pcc_quantize_symbols")
+        return sym
 
     def gaussian_quant16(self, y, params, scale, table):
         """compact form: int16 symbols, uint8 indexes, overflow flag (device int32[1])"""

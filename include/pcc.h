@@ -241,6 +241,14 @@ int pcc_gaussian_quant(pcc_ctx* ctx, const float* d_y, const float* d_params,
                        int64_t n, int c, const float* d_scale, int q,
                        const float* d_table, int n_tab, int32_t* d_sym,
                        int32_t* d_idx);
+/* element-wise forms behind the CompressAI-shaped tensor methods
+ * gaussian_conditional.build_indexes(t) and EntropyModel.quantize(t, "symbols",
+ * means) (any shape, n elements): idx = build_indexes(scales); sym = rint(x -
+ * means) (means nullable). */
+int pcc_build_indexes(pcc_ctx* ctx, const float* d_scales, int64_t n,
+                      const float* d_table, int n_tab, int32_t* d_idx);
+int pcc_quantize_symbols(pcc_ctx* ctx, const float* d_x, const float* d_means,
+                         int64_t n, int32_t* d_sym);
 /* compact form of the same: int16 symbols, uint8 indexes (3 instead of 8 bytes
  * per symbol across PCIe).  d_flag (int32[1]) is OR-ed with 1 if a symbol does
  * not fit int16; the caller then falls back to pcc_gaussian_quant. */

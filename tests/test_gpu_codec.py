@@ -125,6 +125,40 @@ def test_device_resident_inputs_give_same_bytes(enc, wl):
     assert out[1] == ref[1] and out[3] == ref[3]
 
 
+def test_compressai_shaped_entropy_surface(enc, oracle):
+    """the tensor-level calls the reference makes (codec_pipeline.py:407-430, codec_parallel.py:398-400,
+    :305-307) give the same strings as the fused row path and the oracle"""
+    rng = np.random.default_rng(31)
+    n, c, nq = 700, 32, 3
+    y = (rng.normal(size=(n, c)) * 2).astype(np.float32)
+    params = np.concatenate([np.abs(rng.normal(1.5, 1.0, (n, c))), rng.normal(0, 1, (n, c))], 1).astype(np.float32)
+    scale = (oracle.scale_nn(SETTINGS) + oracle.eps).astype(np.float32)
+    rt = enc.runtimes[0]
+    em = enc.compression_model.entropy_model
+    gc, eb = em.gaussian_conditional, em.entropy_bottleneck
+    with rt:
+        scales_hat = torch.from_numpy(params[:, :c].T.copy()).unsqueeze(0).repeat(nq, 1, 1)
+        means_hat = torch.from_numpy(params[:, c:].T.copy()).unsqueeze(0).repeat(nq, 1, 1)
+        scale_t = torch.from_numpy(scale).unsqueeze(2).repeat(1, 1, n)
+        indexes = gc.build_indexes(scales_hat * scale_t)
+        strings = gc.compress(torch.from_numpy(y.T.copy()).unsqueeze(0).repeat(nq, 1, 1) * scale_t, indexes,
+                              means=means_hat * scale_t)
+        fused = gc.compress_rows(rt, rt.to_device(y), rt.to_device(params), rt.to_device(scale))
+        rs, ri = oracle.gaussian_quant(y, params, scale)
+        assert np.array_equal(indexes.cpu().numpy(), ri)
+        assert strings == fused == [oracle.rans_encode(rs[q], ri[q], "gaussian_conditional") for q in range(nq)]
+        back = gc.decompress([strings[1]], indexes[1:2])
+        assert back.dtype == torch.float32 and np.array_equal(back.cpu().numpy()[0], rs[1].astype(np.float32))
+        assert float(gc.lower_bound_scale(torch.tensor([0.01, 3.0])).min()) == pytest.approx(0.11, abs=1e-6)
+        # factorized bottleneck, [1, C, N] tensors
+        z = (rng.normal(size=(40, c)) * 3).astype(np.float32)
+        zs = eb.compress(torch.from_numpy(z.T.copy()).unsqueeze(0))
+        zsym, zhat = oracle.factorized_quant(z)
+        assert zs == [oracle.rans_encode(zsym, np.repeat(np.arange(c, dtype=np.int32), 40), "entropy_bottleneck")]
+        zh = eb.decompress(zs, [40])
+        assert tuple(zh.shape) == (1, c, 40) and np.array_equal(zh.cpu().numpy()[0].T, zhat)
+
+
 def test_errors(enc, dec, wl):
     runtime = pkg("runtime")
     f = wl.sphere_shell(24, 9.1, seed=9)
