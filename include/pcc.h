@@ -334,6 +334,35 @@ int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points,
 int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_points,
                       int64_t cap_points);
 
+/* ---- capture pre-step ------------------------------- */
+
+/* replaces: the voxelisation the capturer does per camera frame with numpy +
+ * Open3D (sender/capturer/capturer.py:88-126).  Input: ZED XYZRGBA float32
+ * [m,4] (colour packed in the 4th float, r = bits 0-7, g = 8-15, b = 16-23).
+ *  pcc_vox_valid : valid[i] = finite && norm <= depth_clip; returns the
+ *                  per-axis minimum of the valid points and their number
+ *  pcc_vox_keys  : Open3D voxel index of every valid point packed as
+ *                  ix<<42|iy<<21|iz (all ones for invalid points); d_flag is
+ *                  OR-ed with 1 if an index does not fit 21 bits
+ *  pcc_vox_mean  : on keys sorted with pcc_sort_pairs (d_perm = its permutation,
+ *                  first n_valid entries): per voxel, mean position / colour in
+ *                  double (input order) -> integer voxel rint(mean/voxel_size)
+ *                  as rows (0,x,y,z) and float64 colours in [0,1]
+ *  pcc_unique_rows: indices of the first row of every run of equal rows in an
+ *                  array sorted so that duplicates are adjacent */
+int pcc_vox_valid(pcc_ctx* ctx, const float* d_xyzrgba, int64_t m,
+                  float depth_clip, uint8_t* d_valid, float* h_min_bound,
+                  int64_t* h_n_valid);
+int pcc_vox_keys(pcc_ctx* ctx, const float* d_xyzrgba, const uint8_t* d_valid,
+                 int64_t m, const double* h_voxel_min_bound, double voxel_size,
+                 uint64_t* d_keys, int32_t* d_flag);
+int pcc_vox_mean(pcc_ctx* ctx, const float* d_xyzrgba,
+                 const uint64_t* d_sorted_keys, const uint32_t* d_perm,
+                 int64_t n_valid, double voxel_size, int32_t* d_out_coords,
+                 double* d_out_colors, int64_t cap, int64_t* h_n_voxels);
+int pcc_unique_rows(pcc_ctx* ctx, const int32_t* d_sorted_coords, int64_t n,
+                    uint32_t* d_rows, int64_t* h_n_unique);
+
 #ifdef __cplusplus
 }
 #endif
