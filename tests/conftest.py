@@ -23,7 +23,8 @@ def pkg(sub=None):
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.codec_ref import Oracle
-    return Oracle()
+    # size the oracle's OpenMP pool to the cgroup share (the GPU boxes show 256 cores, grant 16)
+    return Oracle(threads=min(8, pkg("_abi").host_cpu_budget()))
 
 
 @pytest.fixture(scope="session")
