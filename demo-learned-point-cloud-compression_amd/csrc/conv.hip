@@ -239,6 +239,8 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma_pipe(
   }
 }
 
+#include "conv_compact.h"
+
 // scalar-fmaf reference path on the GPU (any cin/cout), same bits as the MFMA path
 __global__ __launch_bounds__(256) void k_gconv_scalar(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
@@ -398,6 +400,29 @@ static bool force_scalar() {
   return v == 1;
 }
 
+// PCC_CONV_COMPACT = 0 | 64 | 128: rows per wave of the row-compacting 32->32 kernel (0 = dense tiles)
+static int compact_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PCC_CONV_COMPACT");
+    v = e ? atoi(e) : 64;
+    if (v != 0 && v != 64 && v != 128) v = 64;
+  }
+  return v;
+}
+
+template <bool HEAD>
+static void launch_compact(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
+                           int64_t n_out, const float* d_w, const float* d_bias, int relu, float* d_out,
+                           const float* hw, const float* hb, float* ho) {
+  if (compact_rows() == 64)
+    hipLaunchKernelGGL((k_gconv_mfma_compact<1, HEAD>), dim3(nblk(n_out, 64)), dim3(64), 0, st, d_in, d_nbr,
+                       k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
+  else
+    hipLaunchKernelGGL((k_gconv_mfma_compact<2, HEAD>), dim3(nblk(n_out, 128)), dim3(64), 0, st, d_in, d_nbr,
+                       k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
+}
+
 extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
                                int k_vol, int64_t nbr_pitch, int64_t n_out, const float* d_w,
                                const float* d_bias, int cin, int cout, int relu, float* d_out) {
@@ -416,7 +441,10 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   static const bool simple = [] { const char* e = getenv("PCC_CONV_SIMPLE"); return e && e[0] == '1'; }();
   const float* nof = nullptr;
   float* nofo = nullptr;
-  if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32) {
+  if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32 && compact_rows() != 0 &&
+      (uintptr_t)d_out % 16 == 0) {
+    launch_compact<false>(st, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);
+  } else if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32) {
     hipLaunchKernelGGL((k_gconv_mfma_pipe<1, false>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr,
                        k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);
   } else if (!force_scalar() && !simple && aligned && cin == 32 && cout == 64) {
@@ -449,9 +477,13 @@ extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_i
   if (n_out > 0 && !force_scalar() && aligned && cin == 32 && cout == 32 && (k_vol == 27 || k_vol == 8) &&
       d_in && d_nbr && d_w && d_bias && d_out && nbr_pitch >= n_out && n_in > 0) {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
-    hipLaunchKernelGGL((k_gconv_mfma_pipe<1, true>), dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0,
-                       ctx->stream, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
-                       d_head_b, d_head_out);
+    if (compact_rows() != 0 && (uintptr_t)d_out % 16 == 0)
+      launch_compact<true>(ctx->stream, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
+                           d_head_b, d_head_out);
+    else
+      hipLaunchKernelGGL((k_gconv_mfma_pipe<1, true>), dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0,
+                         ctx->stream, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
+                         d_head_b, d_head_out);
     PCC_CHECK_LAUNCH();
     return PCC_OK;
   }

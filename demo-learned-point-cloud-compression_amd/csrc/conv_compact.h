@@ -1,0 +1,201 @@
+// conv_compact.h — row-compacting form of the 32->32 gather-convolution (included by conv.hip).
+//
+// The out-stationary kernels in conv.hip spend one 32-row MFMA tile on every offset that ANY of the
+// tile's rows has, so on surface data roughly half of the matrix-core work multiplies zero rows
+// (measured: SQ_INSTS_MFMA == 27 offsets x all tiles; useful pairs / issued pairs = 0.53).  Here a wave
+// owns R = 64 or 128 consecutive (Morton-sorted) output rows and, offset by offset, packs only the
+// rows that HAVE the neighbour into 32-row groups:
+//
+//   for k ascending:  slots = compact(rows of the window whose nbr[k] >= 0)      (ballot + mbcnt)
+//                     for each group of 32 slots:  C  <- accumulators of those rows (LDS, 4 x b128)
+//                                                  C  += W[k]^T  x  X_gathered^T   (16 MFMA 32x32x2)
+//                                                  accumulators <- C
+//
+// The product is computed transposed (M = output channel, N = row slot) so that one lane holds 16
+// channels of ONE row: reading / writing a row's accumulator is 4 ds_read_b128 / ds_write_b128 at
+// row*36 floats (pitch 36 keeps 16 consecutive rows on distinct banks), about 8 KB of LDS traffic per
+// 1024 MFMA cycles.  Per output row the arithmetic is still
+//   out = bias; for k ascending over PRESENT neighbours, ci ascending: out = fmaf(x, w, out)
+// (a row simply does not take part in the groups of an offset it lacks), so the bits equal those of
+// the dense-tile kernels, the scalar kernel and the C oracle.  Pad slots of a partly filled last
+// group gather zeros and accumulate into a sink row.
+//
+// Pipeline per wave: neighbour indices of offset k+2 are in flight (registers) while offset k+1 is
+// being compacted and offset k is contracted; the gathered rows of ALL groups of offset k+1 (4 x
+// dwordx4 per lane and group, up to R*128 B per wave) and its 16 weight dwords are in flight while
+// the groups of offset k run, each group's registers being refilled as soon as it has been staged.
+#pragma once
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int RCH, bool HEAD>
+__global__ __launch_bounds__(64) void k_gconv_mfma_compact(
+    const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+    int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+    float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ head_out) {
+  constexpr int R = 64 * RCH;  // output rows of this wave
+  constexpr int AP = 36;       // accumulator row pitch (floats), 16-B aligned rows
+  __shared__ __attribute__((aligned(16))) float acc_lds[(R + 1) * AP];  // row R = sink for pad slots
+  __shared__ int32_t slot_in[2][R];
+  __shared__ uint8_t slot_row[2][R];
+
+  const int lane = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int i = lane & 31, h = lane >> 5;
+  const int grow = lane >> 3, chunk = lane & 7;
+
+  // ---- accumulators start at the bias
+  {
+    const float4 b4 = make_float4(bias[chunk * 4], bias[chunk * 4 + 1], bias[chunk * 4 + 2], bias[chunk * 4 + 3]);
+#pragma unroll
+    for (int it = 0; it < R / 8; ++it)
+      *reinterpret_cast<float4*>(&acc_lds[(it * 8 + grow) * AP + chunk * 4]) = b4;
+    if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[R * AP + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  int32_t nbreg[RCH];
+  auto load_nb = [&](int k) {
+#pragma unroll
+    for (int c = 0; c < RCH; ++c) {  // branch-free (clamped address + select): keeps the loads out of control flow
+      const int64_t r = row0 + c * 64 + lane;
+      const int32_t v = nbr[(int64_t)(k < k_vol ? k : k_vol - 1) * pitch + (r < n_out ? r : n_out - 1)];
+      nbreg[c] = (k < k_vol && r < n_out) ? v : -1;
+    }
+  };
+  // pack the rows that have the offset held in nbreg into slot lists `b`; returns their count
+  auto compact = [&](int b) -> int {
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < RCH; ++c) {
+      const bool p = nbreg[c] >= 0;
+      const unsigned long long bal = __ballot(p);
+      const int rank = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+      if (p) {
+        slot_in[b][rank] = nbreg[c];
+        slot_row[b][rank] = (uint8_t)(c * 64 + lane);
+      }
+      cnt += __popcll(bal);
+    }
+    // every remaining slot is a pad: row 0 of `in` (any valid row), accumulated into the sink row
+#pragma unroll
+    for (int c = 0; c < RCH; ++c) {
+      const int sl = cnt + c * 64 + lane;
+      if (sl < R) {
+        slot_in[b][sl] = 0;
+        slot_row[b][sl] = (uint8_t)R;
+      }
+    }
+    return cnt;
+  };
+
+  constexpr int NG = R / 32;  // groups an offset can have
+  // gathered rows of every group of an offset: two register sets, even offsets use gA, odd ones gB,
+  // so the set of offset k+1 fills (whole offset in flight) while the groups of offset k are contracted
+  float4 gA[NG][4], gB[NG][4];
+  float bw[16];
+  auto load_w = [&](int k) {
+    const float* wk = w + (int64_t)k * 32 * 32;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bw[s] = wk[(2 * s + h) * 32 + i];
+  };
+
+#define PCC_WAVE_SYNC()                                      \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+// pad slots carry row 0 (any valid row: their products go to the sink row)
+#define PCC_GATHER(G, b, cnt)                                                                      \
+  do {                                                                                             \
+    _Pragma("unroll") for (int grp = 0; grp < NG; ++grp) {                                         \
+      const float* xr = in + (int64_t)slot_in[b][grp * 32 + i] * 32 + h * 16;                      \
+      _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
+        G[grp][it] = *reinterpret_cast<const float4*>(xr + it * 4);                                \
+    }                                                                                              \
+  } while (0)
+// one offset: compact offset k+1, put its rows in flight into GN, contract the groups held in GC
+#define PCC_STEP(GC, GN, cur, k)                                                                   \
+  do {                                                                                             \
+    const int cnt_next = compact((cur) ^ 1); /* offset k+1 (all absent past the last offset) */    \
+    load_nb((k) + 2);                                                                              \
+    PCC_WAVE_SYNC();                                                                               \
+    float bc[16];                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 16; ++s) bc[s] = bw[s];                                  \
+    load_w((k) + 1 < k_vol ? (k) + 1 : (k));                                                       \
+    PCC_GATHER(GN, (cur) ^ 1, cnt_next);                                                           \
+    _Pragma("unroll") for (int grp = 0; grp < NG; ++grp) {                                         \
+      if (grp * 32 < cnt_cur) {                                                                    \
+        const int arow = (int)slot_row[cur][grp * 32 + i];                                         \
+        float* ap = &acc_lds[arow * AP + h * 4];                                                   \
+        f32x16 acc;                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+          const float4 c4 = *reinterpret_cast<const float4*>(ap + j * 8);                          \
+          acc[4 * j + 0] = c4.x; acc[4 * j + 1] = c4.y; acc[4 * j + 2] = c4.z; acc[4 * j + 3] = c4.w; \
+        }                                                                                          \
+        /* lane (i,h) holds x[slot i][16h .. 16h+15]; the MFMA wants x[slot i][2s+h]: swapping the */ \
+        /* upper half of the even-j register with the lower half of the odd-j one gives both       */ \
+        /* ci = 2t+h (s = t) and ci = 16+2t+h (s = 8+t) without touching LDS                       */ \
+        float xv[16];                                                                              \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                         \
+          const u32x2 p0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(GC[grp][it].x),        \
+                                                            __float_as_uint(GC[grp][it].y), false, false); \
+          const u32x2 p1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(GC[grp][it].z),        \
+                                                            __float_as_uint(GC[grp][it].w), false, false); \
+          xv[2 * it] = __uint_as_float(p0[0]);     xv[8 + 2 * it] = __uint_as_float(p0[1]);        \
+          xv[2 * it + 1] = __uint_as_float(p1[0]); xv[8 + 2 * it + 1] = __uint_as_float(p1[1]);    \
+        }                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 16; ++s)                                             \
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s], xv[s], acc, 0, 0, 0);                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+          *reinterpret_cast<float4*>(ap + j * 8) =                                                 \
+              make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);         \
+        PCC_WAVE_SYNC();                                                                           \
+      }                                                                                            \
+    }                                                                                              \
+    cnt_cur = cnt_next;                                                                            \
+  } while (0)
+
+  load_nb(0);
+  int cnt_cur = compact(0);
+  load_nb(1);
+  PCC_WAVE_SYNC();
+  PCC_GATHER(gA, 0, cnt_cur);
+  load_w(0);
+
+  // D[co][slot] += sum_ci W[ci][co] * x[slot][ci], 2 ci per MFMA, ci ascending
+  for (int k = 0; k < k_vol; k += 2) {
+    PCC_STEP(gA, gB, 0, k);
+    if (k + 1 < k_vol) PCC_STEP(gB, gA, 1, k + 1);
+  }
+#undef PCC_STEP
+#undef PCC_GATHER
+
+  // ---- epilogue: the window's rows are contiguous in `out`: coalesced 16-B stores
+#pragma unroll
+  for (int it = 0; it < R / 8; ++it) {
+    const int r = it * 8 + grow;
+    float4 v = *reinterpret_cast<const float4*>(&acc_lds[r * AP + chunk * 4]);
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
+  }
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int c = 0; c < RCH; ++c) {
+      const int r = c * 64 + lane;
+      float hv = head_b[0];
+#pragma unroll
+      for (int ch = 0; ch < 32; ++ch) {
+        float v = acc_lds[r * AP + ch];
+        if (relu) v = fmaxf(v, 0.f);
+        hv = fmaf(v, head_w[ch], hv);
+      }
+      if (row0 + r < n_out) head_out[row0 + r] = hv;
+    }
+  }
+#undef PCC_WAVE_SYNC
+}
