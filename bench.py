@@ -210,9 +210,10 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             kname = {"sparse_conv": "k_gconv_mfma", "convT_gen": "k_convT_mfma"}[op]
-            grid = ((n_out + 127) // 128) * 256
+            # grid of the dense-tile kernels (4 waves x 32 rows) or of the row-compacting one (1 wave x 64 rows)
+            grids = (((n_out + 127) // 128) * 256, ((n_out + 63) // 64) * 64)
             for rec in pmc["kernels"]:
-                if kname in rec["kernel"] and rec["grid_threads"] == grid:
+                if kname in rec["kernel"] and rec["grid_threads"] in grids:
                     roofline["traffic"] = rec["hbm_bytes_corrected"]
                     roofline["traffic_source"] = "profiles/pmc_latest.json: (2*FETCH_SIZE+WRITE_SIZE)*1024"
                     break

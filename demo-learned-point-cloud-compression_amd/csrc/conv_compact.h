@@ -17,13 +17,26 @@
 // 1024 MFMA cycles.  Per output row the arithmetic is still
 //   out = bias; for k ascending over PRESENT neighbours, ci ascending: out = fmaf(x, w, out)
 // (a row simply does not take part in the groups of an offset it lacks), so the bits equal those of
-// the dense-tile kernels, the scalar kernel and the C oracle.  Pad slots of a partly filled last
-// group gather zeros and accumulate into a sink row.
+// the dense-tile kernels, the scalar kernel and the C oracle.  Pad slots (the rest of a partly filled
+// group, and a group with no present row at all) gather row 0 of the input and accumulate into a
+// sink row that is never stored: every load is unconditional, which keeps the loads out of control
+// flow so that the compiler's s_waitcnt counts stay exact (vmcnt(N), not vmcnt(0)).
+//
+// Operand shaping without LDS: lane (i, h) loads the 64-B half h of the neighbour row of slot i
+// (x[16h .. 16h+15]); the MFMA wants x[2s + h] in step s.  v_permlane32_swap of the even-j register's
+// upper half with the odd-j register's lower half yields both ci = 2t+h (step t) and ci = 16+2t+h
+// (step 8+t) in place: 8 swaps per group, which the compiler slots between the MFMAs.
 //
 // Pipeline per wave: neighbour indices of offset k+2 are in flight (registers) while offset k+1 is
 // being compacted and offset k is contracted; the gathered rows of ALL groups of offset k+1 (4 x
-// dwordx4 per lane and group, up to R*128 B per wave) and its 16 weight dwords are in flight while
-// the groups of offset k run, each group's registers being refilled as soon as it has been staged.
+// dwordx4 per lane and group) and its 16 weight dwords go in flight into a second register set
+// (sets alternate between even and odd offsets) before the groups of offset k run.
+//
+// Measured on the 3,262,640-row layer of bench.py (tools/bench_conv.py, MI355X): dense tiles 1.69-1.80
+// ms, this kernel 1.40-1.49 ms with R = 64 (R = 128 the same within 1 %: fewer weight re-reads,
+// lower occupancy).  Variants that were measured and dropped: gathered rows staged through an LDS
+// tile (1.70 ms: 16 ds_write + 16 ds_read per group), compaction by ds_permute with the slot lists in
+// registers (1.83-1.87 ms) and a single weight register set reloaded behind its last reader (1.72 ms).
 #pragma once
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
