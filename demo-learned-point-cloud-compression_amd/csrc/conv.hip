@@ -415,12 +415,13 @@ template <bool HEAD>
 static void launch_compact(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
                            int64_t n_out, const float* d_w, const float* d_bias, int relu, float* d_out,
                            const float* hw, const float* hb, float* ho) {
+  // grid rounded up to a multiple of 8: the kernel maps workgroup -> window per XCD
   if (compact_rows() == 64)
-    hipLaunchKernelGGL((k_gconv_mfma_compact<1, HEAD>), dim3(nblk(n_out, 64)), dim3(64), 0, st, d_in, d_nbr,
-                       k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
+    hipLaunchKernelGGL((k_gconv_mfma_compact<1, HEAD>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0, st, d_in,
+                       d_nbr, k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
   else
-    hipLaunchKernelGGL((k_gconv_mfma_compact<2, HEAD>), dim3(nblk(n_out, 128)), dim3(64), 0, st, d_in, d_nbr,
-                       k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
+    hipLaunchKernelGGL((k_gconv_mfma_compact<2, HEAD>), dim3((nblk(n_out, 128) + 7) / 8 * 8), dim3(64), 0, st, d_in,
+                       d_nbr, k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
 }
 
 extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,

@@ -54,7 +54,12 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
   __shared__ uint8_t slot_row[2][R];
 
   const int lane = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * R;
+  // XCD-aware window order: workgroups are dealt round-robin to the 8 XCDs, so workgroup b works on
+  // window (b % 8) * (grid / 8) + b / 8: every XCD walks one contiguous eighth of the (Morton-sorted)
+  // rows, and the neighbour rows that adjacent windows share are fetched into ONE L2 instead of eight
+  const int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t row0 = window * R;
+  if (row0 >= n_out) return;  // the grid is rounded up to a multiple of 8
   const int i = lane & 31, h = lane >> 5;
   const int grow = lane >> 3, chunk = lane & 7;
 

@@ -18,9 +18,10 @@
 // Two element widths cross the boundary: int32 symbols / int32 indexes (generic)
 // and int16 symbols / uint8 indexes (what the device kernels emit for the y
 // latents: 3 instead of 8 bytes per symbol over PCIe).  The decoder resolves the
-// symbol with a 256-entry per-table lookup on the top 8 bits of the cumulative
+// symbol with a 1024-entry per-table lookup on the top 10 bits of the cumulative
 // frequency followed by a short forward scan (same result as CompressAI's linear
-// std::find_if over the CDF).
+// std::find_if over the CDF); the encoder works from per-symbol entries holding
+// start, frequency, its exact reciprocal and the renormalisation threshold.
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
@@ -77,6 +78,9 @@ struct Enc {
     const uint64_t q = (t + ((x - t) >> r.sh1)) >> r.sh2;   // == x / freq
     x = (q << kPrecision) + (x - q * freq) + start;
   }
+  // same step from a precomputed per-symbol entry (one 32-byte load instead of cdf[v], cdf[v+1] and
+  // the 1 MB reciprocal table)
+  inline void put(const struct EncSym& e);
   inline void put_bits(uint32_t val) {
     const uint32_t freq = 1u << (16 - kBypassBits);
     const uint64_t x_max = ((kRansL >> 16) << 32) * freq;
@@ -84,6 +88,19 @@ struct Enc {
     x = (x << kBypassBits) | val;
   }
 };
+
+struct EncSym {
+  uint64_t m;       // reciprocal multiplier of freq
+  uint64_t x_max;   // renormalisation threshold ((L >> 16) << 32) * freq
+  uint32_t start, freq;
+  uint8_t sh1, sh2;
+};
+inline void Enc::put(const EncSym& e) {
+  if (x >= e.x_max) { emit((uint32_t)x); x >>= 32; }
+  const uint64_t t = (uint64_t)(((unsigned __int128)e.m * x) >> 64);
+  const uint64_t q = (t + ((x - t) >> e.sh1)) >> e.sh2;   // == x / freq
+  x = (q << kPrecision) + (x - q * e.freq) + e.start;
+}
 
 inline int n_nibbles(uint32_t raw) {
   int nb = 0;
@@ -99,6 +116,28 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
   // one 32-bit word, and in-range symbols (the common case) emit 16 bits on average.  Size the
   // staging buffer for the common case and grow on demand.
   std::vector<uint32_t> buf((size_t)(n / 2 + n / 8) + 1024);
+  // per-table symbol entries (tables are small: sum of sizes is a few thousand)
+  std::vector<int32_t> base((size_t)n_cdf + 1, 0);
+  for (int c = 0; c < n_cdf; ++c) {
+    if (sizes[c] < 2 || sizes[c] > pitch) {
+      snprintf(err, errlen, "rans encode: cdf %d has length %d", c, sizes[c]);
+      return PCC_E_ARG;
+    }
+    base[c + 1] = base[c] + sizes[c] - 1;
+  }
+  std::vector<EncSym> ent((size_t)base[n_cdf]);
+  for (int c = 0; c < n_cdf; ++c) {
+    const int32_t* cdf = cdfs + (int64_t)c * pitch;
+    for (int v = 0; v < sizes[c] - 1; ++v) {
+      EncSym& e = ent[(size_t)base[c] + v];
+      const int64_t f = (int64_t)cdf[v + 1] - cdf[v];
+      e.start = (uint32_t)cdf[v];
+      e.freq = (f >= 1 && f <= 65536) ? (uint32_t)f : 0u;   // 0 marks an unusable bin (checked at use)
+      const Rcp& r = g_rcp[e.freq ? e.freq : 1];
+      e.m = r.m; e.sh1 = r.sh1; e.sh2 = r.sh2;
+      e.x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)e.freq;
+    }
+  }
   for (int attempt = 0; attempt < 3; ++attempt) {
     Enc e;
     e.x = kRansL;
@@ -111,7 +150,6 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
         snprintf(err, errlen, "rans encode: index %d out of range at %lld", ci, (long long)i);
         return PCC_E_ARG;
       }
-      const int32_t* cdf = cdfs + (int64_t)ci * pitch;
       const int32_t max_value = sizes[ci] - 2;
       int32_t value = (int32_t)sym[i] - offsets[ci];
       if ((uint32_t)value >= (uint32_t)max_value) {
@@ -127,13 +165,12 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
         e.put_bits((uint32_t)(nb - full * (int)kMaxBypass));
         for (int j = 0; j < full; ++j) e.put_bits(kMaxBypass);
       }
-      const uint32_t start = (uint32_t)cdf[value];
-      const uint32_t freq = (uint32_t)(cdf[value + 1] - cdf[value]);
-      if (freq == 0) {
+      const EncSym& es = ent[(size_t)base[ci] + value];
+      if (es.freq == 0) {
         snprintf(err, errlen, "rans encode: zero frequency (cdf %d, value %d)", ci, value);
         return PCC_E_ARG;
       }
-      e.put(start, freq);
+      e.put(es);
     }
     // flush: two words, low then high
     e.emit((uint32_t)(e.x >> 32));
@@ -184,12 +221,15 @@ int encode_multi(const SymT* h_sym, const IdxT* h_idx, int64_t n, int n_streams,
   return PCC_OK;
 }
 
+// Decoder tables, built once per call (a few thousand entries): sym[s] = freq << 16 | start, and a
+// 1024-entry lookup on the top 10 bits of the cumulative frequency giving the first candidate symbol;
+// a short forward scan finishes it (same result as CompressAI's linear std::find_if over the CDF).
 struct DecTab {
-  const int32_t* cdf;
-  int32_t size, max_value, offset;
-  bool built;
-  uint16_t lut[256];
+  const uint32_t* sym;   // [size - 1]
+  const uint16_t* lut;   // [1024]
+  int32_t max_value, offset;
 };
+constexpr int kLutBits = 10;
 
 template <typename IdxT>
 int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n, const int32_t* h_cdfs,
@@ -200,13 +240,51 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
     pcc_set_error("%s: bad argument (len=%lld)", who, (long long)len);
     return len < 8 ? PCC_E_STREAM : PCC_E_ARG;
   }
+  // ---- indexes are validated up front (keeps the check out of the serial loop)
+  {
+    uint32_t worst = 0;
+    for (int64_t i = 0; i < n; ++i) worst = std::max(worst, (uint32_t)(int32_t)h_idx[i]);
+    if (n > 0 && worst >= (uint32_t)n_cdf) {
+      for (int64_t i = 0; i < n; ++i)
+        if ((uint32_t)(int32_t)h_idx[i] >= (uint32_t)n_cdf) {
+          pcc_set_error("%s: index %d out of range at %lld", who, (int32_t)h_idx[i], (long long)i);
+          return PCC_E_ARG;
+        }
+    }
+  }
+  // ---- tables of the CDFs that are in use
+  std::vector<uint8_t> used((size_t)n_cdf, 0);
+  for (int64_t i = 0; i < n; ++i) used[(size_t)(int32_t)h_idx[i]] = 1;
   std::vector<DecTab> tabs((size_t)n_cdf);
+  std::vector<uint16_t> luts((size_t)n_cdf << kLutBits);
+  size_t total = 0;
   for (int c = 0; c < n_cdf; ++c) {
-    tabs[c].cdf = h_cdfs + (int64_t)c * cdf_pitch;
-    tabs[c].size = h_sizes[c];
-    tabs[c].max_value = h_sizes[c] - 2;
+    if (!used[c]) continue;
+    if (h_sizes[c] < 2 || h_sizes[c] > cdf_pitch) {
+      pcc_set_error("%s: cdf %d has length %d", who, c, h_sizes[c]);
+      return PCC_E_ARG;
+    }
+    total += (size_t)h_sizes[c] - 1;
+  }
+  std::vector<uint32_t> syms(total + 1);
+  total = 0;
+  for (int c = 0; c < n_cdf; ++c) {
+    if (!used[c]) continue;
+    const int32_t* cdf = h_cdfs + (int64_t)c * cdf_pitch;
+    const int size = h_sizes[c];
+    uint32_t* sy = syms.data() + total;
+    for (int v = 0; v < size - 1; ++v) sy[v] = ((uint32_t)(cdf[v + 1] - cdf[v]) << 16) | ((uint32_t)cdf[v] & 0xFFFFu);
+    uint16_t* lut = luts.data() + ((size_t)c << kLutBits);
+    int s = 0;  // lut[b] = largest s <= max_value with cdf[s] <= b << (16 - kLutBits)
+    for (int b = 0; b < (1 << kLutBits); ++b) {
+      while (s + 1 < size - 1 && cdf[s + 1] <= (b << (16 - kLutBits))) ++s;
+      lut[b] = (uint16_t)s;
+    }
+    tabs[c].sym = sy;
+    tabs[c].lut = lut;
+    tabs[c].max_value = size - 2;
     tabs[c].offset = h_offsets[c];
-    tabs[c].built = false;
+    total += (size_t)size - 1;
   }
   const uint8_t* p = h_in;
   const uint8_t* const end = h_in + len;
@@ -221,34 +299,16 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
   uint64_t x = word(bad);
   x |= (uint64_t)word(bad) << 32;
   for (int64_t i = 0; i < n; ++i) {
-    const int32_t ci = (int32_t)h_idx[i];
-    if ((uint32_t)ci >= (uint32_t)n_cdf) {
-      pcc_set_error("%s: index %d out of range at %lld", who, ci, (long long)i);
-      return PCC_E_ARG;
-    }
-    DecTab& t = tabs[ci];
-    if (!t.built) {
-      if (t.size < 2 || t.size > cdf_pitch) {
-        pcc_set_error("%s: cdf %d has length %d", who, ci, t.size);
-        return PCC_E_ARG;
-      }
-      // lut[b] = largest s with cdf[s] <= b<<8
-      int s = 0;
-      for (int b = 0; b < 256; ++b) {
-        while (s + 1 < t.size - 1 && t.cdf[s + 1] <= (b << 8)) ++s;
-        t.lut[b] = (uint16_t)s;
-      }
-      t.built = true;
-    }
+    const DecTab& t = tabs[(size_t)(int32_t)h_idx[i]];
     const uint32_t cum = (uint32_t)(x & 0xFFFFu);
-    int32_t s = t.lut[cum >> 8];
-    while (s < t.max_value && (uint32_t)t.cdf[s + 1] <= cum) ++s;  // == find_if(v > cum) - 1
-    const uint32_t start = (uint32_t)t.cdf[s];
-    const uint32_t freq = (uint32_t)(t.cdf[s + 1] - t.cdf[s]);
-    x = (uint64_t)freq * (x >> kPrecision) + cum - start;
+    int32_t s = t.lut[cum >> (16 - kLutBits)];
+    // forward scan: entry s+1 starts at (sym[s+1] & 0xFFFF); == find_if(v > cum) - 1
+    while (s < t.max_value && (t.sym[s + 1] & 0xFFFFu) <= cum) ++s;
+    const uint32_t e = t.sym[s];
+    x = (uint64_t)(e >> 16) * (x >> kPrecision) + cum - (e & 0xFFFFu);
     if (x < kRansL) x = (x << 32) | word(bad);
     int32_t value = s;
-    if (value == t.max_value) {
+    if (__builtin_expect(value == t.max_value, 0)) {
       auto get_bits = [&]() -> uint32_t {
         const uint32_t v = (uint32_t)(x & kMaxBypass);
         x >>= kBypassBits;
@@ -271,11 +331,11 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
       if (raw & 1u) value = -value - 1;
       else value += t.max_value;
     }
-    if (bad) {
-      pcc_set_error("%s: truncated stream at symbol %lld", who, (long long)i);
-      return PCC_E_STREAM;
-    }
     h_sym[i] = value + t.offset;
+  }
+  if (bad) {
+    pcc_set_error("%s: truncated stream", who);
+    return PCC_E_STREAM;
   }
   return PCC_OK;
 }

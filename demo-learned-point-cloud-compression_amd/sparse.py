@@ -68,7 +68,10 @@ class CoordSet:
     def offsets(self):
         """row offsets per batch index (host list of n_batch+1 ints)"""
         if self._offsets is None:
-            self._offsets = self.rt.batch_offsets(self.keys, self.n_batch)
+            if self.n_batch == 1:
+                self._offsets = [0, self.n]      # one frame: nothing to look up on the device
+            else:
+                self._offsets = self.rt.batch_offsets(self.keys, self.n_batch)
         return self._offsets
 
     # ------------------------------------------------------------ rule book

@@ -244,6 +244,71 @@ def test_sparse_conv_fused_head_bit_exact(rt, oracle, clouds, name, cin):
     assert np.array_equal(host(logits), oracle.linear(ref, hw, hb)[:, 0])
 
 
+def _structured_cloud(kind, n):
+    """coordinate sets that exercise the row-compacting 32->32 kernel (64-row windows, groups of 32):
+    dense: a full cube, every offset present for the inner rows (two full groups per offset);
+    dust: isolated voxels, only the centre offset present (single partly filled group, 26 empty offsets);
+    children: all 8 children of scattered stride-2 parents (the decoder's candidate sets);
+    line: a 1-voxel-wide diagonal, 3 offsets present"""
+    rng = np.random.default_rng(n)
+    if kind == "dense":
+        e = int(round(n ** (1 / 3))) + 1
+        g = np.stack(np.meshgrid(np.arange(e), np.arange(e), np.arange(e), indexing="ij"), -1).reshape(-1, 3)[:n]
+        pts = g - e // 2
+    elif kind == "dust":
+        pts = np.unique(rng.integers(-300, 300, (2 * n, 3)) * 3, axis=0)[:n]
+    elif kind == "children":
+        par = np.unique(rng.integers(-12, 12, (n // 8 + 1, 3)), axis=0)
+        offs = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)])
+        pts = (par[:, None, :] * 2 + offs[None]).reshape(-1, 3)[:n]
+    else:
+        t = np.arange(n) - n // 2
+        pts = np.stack([t, t, t], 1)
+    return np.concatenate([np.zeros((pts.shape[0], 1), np.int64), pts], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
+@pytest.mark.parametrize("n", [1, 31, 33, 63, 64, 65, 127, 129, 1000, 4099])
+def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
+    """window / group boundaries of k_gconv_mfma_compact (rows 63|64|65, groups 32|33) on neighbourhoods
+    from empty to full, plain and fused-head entry points, against the oracle's fmaf chain"""
+    rng = np.random.default_rng(1000 + n)
+    keys = sorted_keys(oracle, _structured_cloud(kind, n))
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(len(keys), 32)).astype(np.float32)
+    w, b = _weights(rng, 27, 32, 32)
+    hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
+    hb = rng.normal(0, 0.1, 1).astype(np.float32)
+    ref = oracle.sparse_conv(x, nbr, w, b, False)
+    out = rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), False)
+    assert np.array_equal(host(out), ref)
+    feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw),
+                                        dev(rt, hb))
+    refr = np.maximum(ref, 0)
+    assert np.array_equal(host(feats), refr)
+    assert np.array_equal(host(logits), oracle.linear(refr, hw, hb)[:, 0])
+
+
+def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):
+    """n_in != n_out (stride-2 conv: 8 offsets, input = children, output = parents) and a rule book whose
+    row pitch is larger than n_out: the kernel must honour the pitch and never read past n_out"""
+    rng = np.random.default_rng(5)
+    keys = sorted_keys(oracle, _structured_cloud("children", 3000))
+    pk, nbr8 = oracle.down(keys, 1)
+    x = rng.normal(size=(len(keys), 32)).astype(np.float32)
+    w, b = _weights(rng, 8, 32, 32)
+    ref = oracle.sparse_conv(x, nbr8, w, b, True)
+    wide = np.full((8, nbr8.shape[1] + 37), -1, np.int32)
+    wide[:, :nbr8.shape[1]] = nbr8
+    rtm = pkg("runtime")
+    xd, wide_d, wd, bd = dev(rt, x), dev(rt, wide), dev(rt, w), dev(rt, b)
+    n_out = nbr8.shape[1]
+    out = rt.empty((n_out, 32), torch.float32)
+    rtm.check(rt.lib.pcc_sparse_conv(rt.ctx, rtm._ptr(xd), x.shape[0], rtm._ptr(wide_d), 8, wide.shape[1], n_out,
+                                     rtm._ptr(wd), rtm._ptr(bd), 32, 32, 1, rtm._ptr(out)), "pcc_sparse_conv")
+    assert np.array_equal(host(out), ref)
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (5, 3)])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 700])
 def test_convT_gen_bit_exact(rt, oracle, cin, cout, n):
