@@ -176,14 +176,20 @@ def main():
     if layer_ops and rank == 0:
         (op, dims), (cnt, tot) = layer_ops[0]
         avg_s = tot / cnt / 1e3
-        # one extra untimed step to count the active pairs of every rule book
-        for r in enc.runtimes + dec.runtimes:
+        # one extra untimed step through the op-by-op engine (same kernels, same rule books) to count the
+        # active pairs of every rule book
+        enc_o = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, engine="ops")
+        dec_o = pkg.DecompressionPipeline(device=local, slots=1, output="device", engine="ops")
+        for r in enc_o.runtimes + dec_o.runtimes:
             r.pairs_log = {}
-        step()
+        out_o, _ = enc_o.compress({"frames": [{"points": d_points, "colors": d_colors}], "timestamps": {}})
+        assert out_o[q_dec] == out[q_dec], "the two engines wrote different containers"
+        dec_o.decompress(out_o[q_dec])
         pairs = {}
-        for r in enc.runtimes + dec.runtimes:
+        for r in enc_o.runtimes + dec_o.runtimes:
             pairs.update(r.pairs_log)
             r.pairs_log = None
+        del enc_o, dec_o
         n_out, cin, cout, k_vol = dims
         if op == "sparse_conv" and k_vol == 27:
             p = pairs.get(n_out, 0)
@@ -211,7 +217,8 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             kname = {"sparse_conv": "k_gconv_mfma", "convT_gen": "k_convT_mfma"}[op]
             # grid of the dense-tile kernels (4 waves x 32 rows) or of the row-compacting one (1 wave x 64 rows)
-            grids = (((n_out + 127) // 128) * 256, ((n_out + 63) // 64) * 64)
+            # (its grid is rounded up to a multiple of 8 workgroups for the per-XCD window order)
+            grids = (((n_out + 127) // 128) * 256, ((n_out + 63) // 64) * 64, ((n_out + 63) // 64 + 7) // 8 * 8 * 64)
             for rec in pmc["kernels"]:
                 if kname in rec["kernel"] and rec["grid_threads"] in grids:
                     roofline["traffic"] = rec["hbm_bytes_corrected"]

@@ -24,8 +24,27 @@ class PccError(RuntimeError):
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 pi64, pi32, pf32 = C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_float)
 
+class PccBuf(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("len", C.c_int64)]
+
+
+class PccCloudInfo(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("n_frames", C.c_int32), ("n_offsets", C.c_int32),
+                ("h_offsets", C.POINTER(C.c_int64)), ("d_coords", C.c_void_p), ("d_colors", C.c_void_p),
+                ("q_g", C.c_double), ("q_a", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/pcc.h
 PROTOTYPES = {
+    "pcc_codec_create": (vp, [vp, C.c_size_t, i32, vp]),
+    "pcc_codec_destroy": (None, [vp]),
+    "pcc_codec_ctx": (vp, [vp]),
+    "pcc_encode_gop": (i32, [vp, vp, vp, i64, i32, C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64,
+                             C.POINTER(C.c_double)]),
+    "pcc_decode_gop": (i32, [vp, vp, i64, C.POINTER(PccCloudInfo), C.POINTER(C.c_double)]),
+    "pcc_decode_fetch": (i32, [vp, vp, vp]),
+    "pcc_octree_encode": (i32, [vp, vp, i64, i32, vp, i64, pi64]),
+    "pcc_octree_decode": (i32, [vp, i64, vp, i64, pi64]),
     "pcc_abi_version": (i32, []),
     "pcc_last_error": (C.c_char_p, []),
     "pcc_create": (vp, [i32, vp]),

@@ -17,12 +17,18 @@ import torch
 from . import runtime as _rt
 from . import utils
 from .model import ColorModel
+from .native import NativeCodec
 from .sparse import SparseTensor
 
 
 class DecompressionPipeline:
-    def __init__(self, device=0, slots=3, output="numpy", stage_sync=None):
+    def __init__(self, device=0, slots=3, output="numpy", stage_sync=None, engine=None):
         self.device = torch.device("cuda", device)
+        # "native": one pcc_decode_gop call per container (csrc/codec.hip); "ops": the reference's stage
+        # methods one by one over the op-level C-ABI (same reconstruction, bit for bit)
+        self.engine = engine or os.environ.get("PCC_ENGINE", "native")
+        if self.engine not in ("native", "ops"):
+            raise ValueError(f"engine must be 'native' or 'ops', got {self.engine!r}")
         # stage_sync=True: synchronise the stream at the end of every stage so that dec_time_measurements
         # holds per-stage wall times; False (default, PCC_STAGE_SYNC=1 overrides): stages are enqueued
         # back to back like the reference's asynchronous torch ops and only data hand-overs wait
@@ -31,9 +37,15 @@ class DecompressionPipeline:
         self.decompression_model = self.load_model(base_path)
         self.output = output                  # "numpy" (reference behaviour) or "device"
         self._slots = queue.Queue()
-        self.runtimes = [_rt.Runtime(device) for _ in range(slots)]
-        for r in self.runtimes:
-            self._slots.put(r)
+        if self.engine == "native":
+            self.codecs = [NativeCodec(self.decompression_model.tensors, device) for _ in range(slots)]
+            self.runtimes = [c.rt for c in self.codecs]
+            for c in self.codecs:
+                self._slots.put(c)
+        else:
+            self.runtimes = [_rt.Runtime(device) for _ in range(slots)]
+            for r in self.runtimes:
+                self._slots.put(r)
         self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(2, slots))
 
     def load_model(self, base_path):
@@ -48,6 +60,8 @@ class DecompressionPipeline:
     # ------------------------------------------------------------------ main
     def decompress(self, compressed_data):
         """bitstream reading -> reconstruction (codec_parallel.py:141-171)"""
+        if self.engine == "native":
+            return self._decompress_native(compressed_data)
         t_start = time.time()
         rt = self._slots.get()
         try:
@@ -76,6 +90,29 @@ class DecompressionPipeline:
         sideinfo["timestamps"]["codec_start"] = t_start
         sideinfo["timestamps"]["codec_end"] = time.time()
         return final_data, sideinfo
+
+    def _decompress_native(self, compressed_data):
+        """the same call through pcc_decode_gop; packing as pack_batches (codec_parallel.py:474-502)"""
+        t_start = time.time()
+        codec = self._slots.get()
+        try:
+            with torch.cuda.stream(codec.stream):
+                coords, colors, offs, _, times = codec.decode(bytes(compressed_data))
+                if self.output == "device":
+                    batch = [{"points": coords[offs[i]:offs[i + 1], 1:], "colors": colors[offs[i]:offs[i + 1]]}
+                             for i in range(len(offs) - 1)]
+                else:
+                    points, cols = coords.cpu().numpy(), colors.cpu().numpy()
+                    batch = []
+                    for i in range(len(offs) - 1):
+                        item_colors = np.nan_to_num(cols[offs[i]:offs[i + 1]], nan=0.0)
+                        batch.append({"points": points[offs[i]:offs[i + 1], 1:],
+                                      "colors": np.clip(item_colors * 255.0, 0, 255) / 255})
+        finally:
+            self._slots.put(codec)
+        sideinfo = {"time_measurements": times,
+                    "timestamps": {"codec_start": t_start, "codec_end": time.time()}}
+        return batch, sideinfo
 
     # ------------------------------------------------------------------ stages
     def read_bitstream_batched(self, compressed_data):

@@ -1,0 +1,1195 @@
+// codec.hip — whole-GOP entry points of the C-ABI: pcc_codec_create / pcc_encode_gop / pcc_decode_gop.
+//
+// One call = the whole of CompressionPipeline.compress() (sender/encoder/codec_pipeline.py:196-236)
+// or DecompressionPipeline.decompress() (receiver/decoder/codec_parallel.py:141-171) for one GOP:
+// stage order, coding order, container layout and every arithmetic step are those of the op-level
+// entry points of pcc.h driven in the same sequence (the Python mirror in codec_pipeline.py /
+// codec_parallel.py does exactly that, op by op), so both routes write byte-identical containers
+// and reconstruct identical frames.  What this file adds is the host side in native code: the model
+// graph (DESIGN.md MODEL), coordinate-set bookkeeping, a per-codec device pool instead of a tensor
+// allocator, pinned staging, and the overlap of the serial host coders with the GPU (a helper
+// thread codes the geometry blobs and the z stream while the stream runs h_s and the y symbols; the
+// Q quality streams are coded on Q threads).
+//
+// Host-only code (no kernels); compiled as HIP source for the runtime API.
+#include "common.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <deque>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr int64_t kHashBuildMax = 60000;  // levels up to this many voxels hash directly; larger ones derive
+
+int log2i(int ts) {
+  int s = 0;
+  while ((1 << s) < ts) ++s;
+  return s;
+}
+
+// ---------------------------------------------------------------- checkpoint blob
+// "PCCW" | u32 count | count x { u16 name_len | name | u8 dtype (0 f32, 1 i32) | u8 ndim | u32 dims[ndim]
+//                                | u64 nbytes | pad to 8 | data | pad to 8 }      (little-endian)
+struct Tensor {
+  int dtype = 0;
+  std::vector<int64_t> dims;
+  const uint8_t* data = nullptr;
+  size_t nbytes = 0;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int64_t d : dims) n *= d;
+    return n;
+  }
+  const float* f32() const { return reinterpret_cast<const float*>(data); }
+  const int32_t* i32() const { return reinterpret_cast<const int32_t*>(data); }
+};
+
+// ---------------------------------------------------------------- device pool
+// Tensors of one call come from chained blocks that persist across calls: after the first GOP of a
+// given size no call allocates device memory.
+struct DevPool {
+  struct Block {
+    char* p;
+    size_t cap, off;
+  };
+  std::vector<Block> blocks;
+  void reset() {
+    for (auto& b : blocks) b.off = 0;
+  }
+  void* alloc(size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    for (auto& b : blocks)
+      if (b.cap - b.off >= bytes) {
+        void* r = b.p + b.off;
+        b.off += bytes;
+        return r;
+      }
+    const size_t cap = std::max<size_t>(bytes, (size_t)64 << 20);
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, cap) != hipSuccess) {
+      pcc_set_error("codec pool: hipMalloc(%zu) failed", cap);
+      return nullptr;
+    }
+    blocks.push_back({p, cap, bytes});
+    return p;
+  }
+  void release() {
+    for (auto& b : blocks) (void)hipFree(b.p);
+    blocks.clear();
+  }
+};
+
+struct Pinned {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return PCC_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
+      pcc_set_error("codec: hipHostMalloc(%zu) failed", want);
+      return PCC_E_NOMEM;
+    }
+    cap = want;
+    return PCC_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// ---------------------------------------------------------------- coordinate sets
+struct CS {
+  uint64_t* keys = nullptr;  // device, Morton-sorted, unique
+  int64_t n = 0;
+  int stride = 1;
+  int n_batch = 1;
+  std::vector<int64_t> offsets;  // per-frame row offsets, filled on first use
+  int32_t* nbr27 = nullptr;
+  CS* down = nullptr;  // parents at stride*2 + the kernel-2 rule book [8, down->n]
+  int32_t* nbr8 = nullptr;
+  int32_t* parent_of = nullptr;
+  CS* gen_parent = nullptr;  // set whose generative children these rows are (row 8p+o)
+  CS* subset_of = nullptr;   // candidate set this set was pruned from, with the kept rows
+  uint32_t* keep = nullptr;
+};
+
+struct Feat {  // sparse tensor = coordinate set + feature rows
+  CS* cs = nullptr;
+  float* f = nullptr;
+  int c = 0;
+};
+
+}  // namespace
+
+struct pcc_codec {
+  pcc_ctx* ctx = nullptr;
+  int device = 0;
+  std::vector<uint8_t> blob;
+  std::map<std::string, Tensor> t;
+  std::map<std::string, float*> dev;  // weights / biases / tables in HBM
+  int c_y = 32, c_z = 32;
+  DevPool pool;
+  Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec;
+  std::deque<CS> sets;
+  std::vector<std::vector<uint8_t>> out;  // containers of the last encode
+  // reconstruction of the last decode (device, pool-owned: valid until the next call)
+  int32_t* rec_coords = nullptr;  // [n,4] (b,x,y,z)
+  float* rec_colors = nullptr;    // [n,3]
+  int64_t rec_n = 0;
+  std::vector<int64_t> rec_offsets;
+};
+
+namespace {
+
+#define CODEC_ALLOC(var, type, count)                                        \
+  type* var = (type*)cd->pool.alloc(sizeof(type) * (size_t)(count));         \
+  if (!var) return PCC_E_NOMEM
+
+const Tensor* find(pcc_codec* cd, const std::string& name) {
+  auto it = cd->t.find(name);
+  if (it == cd->t.end()) {
+    pcc_set_error("codec: checkpoint has no tensor '%s'", name.c_str());
+    return nullptr;
+  }
+  return &it->second;
+}
+
+CS* new_set(pcc_codec* cd, uint64_t* keys, int64_t n, int stride, int n_batch) {
+  cd->sets.emplace_back();
+  CS* s = &cd->sets.back();
+  s->keys = keys;
+  s->n = n;
+  s->stride = stride;
+  s->n_batch = n_batch;
+  return s;
+}
+
+int offsets_of(pcc_codec* cd, CS* s, const std::vector<int64_t>** out) {
+  if (s->offsets.empty()) {
+    if (s->n_batch == 1) {
+      s->offsets = {0, s->n};
+    } else if (s->gen_parent) {
+      const std::vector<int64_t>* po;
+      PCC_TRY(offsets_of(cd, s->gen_parent, &po));
+      s->offsets.resize(po->size());
+      for (size_t i = 0; i < po->size(); ++i) s->offsets[i] = 8 * (*po)[i];
+    } else {
+      s->offsets.assign((size_t)s->n_batch + 1, 0);
+      PCC_TRY(pcc_batch_offsets(cd->ctx, s->keys, s->n, s->n_batch, s->offsets.data()));
+    }
+  }
+  *out = &s->offsets;
+  return PCC_OK;
+}
+
+int down_of(pcc_codec* cd, CS* s) {
+  if (s->down) return PCC_OK;
+  const int64_t cap = std::max<int64_t>(s->n, 1);
+  CODEC_ALLOC(pkeys, uint64_t, cap);
+  CODEC_ALLOC(nbr8, int32_t, 8 * cap);
+  CODEC_ALLOC(parent_of, int32_t, cap);
+  int64_t m = 0;
+  if (s->n > 0)
+    PCC_TRY(pcc_down_coords(cd->ctx, s->keys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, &m));
+  s->down = new_set(cd, pkeys, m, s->stride * 2, s->n_batch);
+  s->nbr8 = nbr8;
+  s->parent_of = parent_of;
+  return PCC_OK;
+}
+
+int up_of(pcc_codec* cd, CS* s, CS** out) {
+  if (s->stride < 2) {
+    pcc_set_error("codec: cannot up-sample a stride-1 coordinate set");
+    return PCC_E_ARG;
+  }
+  CODEC_ALLOC(ckeys, uint64_t, std::max<int64_t>(8 * s->n, 1));
+  if (s->n > 0) PCC_TRY(pcc_up_coords(cd->ctx, s->keys, s->n, 3 * (log2i(s->stride) - 1), ckeys));
+  CS* c = new_set(cd, ckeys, 8 * s->n, s->stride / 2, s->n_batch);
+  c->gen_parent = s;
+  *out = c;
+  return PCC_OK;
+}
+
+// 3^3 rule book of a set: derived from the parent level where there is one, hashed only at the
+// coarsest level (sparse.py CoordSet._build_nbr27)
+int nbr27_of(pcc_codec* cd, CS* s, int32_t** out) {
+  if (!s->nbr27) {
+    CODEC_ALLOC(nbr, int32_t, 27 * std::max<int64_t>(s->n, 1));
+    CS* gp = s->gen_parent;
+    if (s->n == 0) {
+      // nothing to fill
+    } else if (gp && gp->n > 0) {
+      if (!gp->nbr27 && gp->subset_of) {
+        CS* cand = gp->subset_of;
+        int32_t* cand_nbr;
+        PCC_TRY(nbr27_of(cd, cand, &cand_nbr));
+        CODEC_ALLOC(remap, int32_t, cand->n);
+        PCC_TRY(pcc_inverse_rows(cd->ctx, gp->keep, gp->n, cand->n, remap));
+        PCC_TRY(pcc_derive_map_up(cd->ctx, cand_nbr, cand->n, gp->keep, remap, gp->n, nbr));
+      } else {
+        int32_t* pn;
+        PCC_TRY(nbr27_of(cd, gp, &pn));
+        PCC_TRY(pcc_derive_map_up(cd->ctx, pn, gp->n, nullptr, nullptr, gp->n, nbr));
+      }
+    } else if (s->n > kHashBuildMax && s->stride <= 4096) {
+      PCC_TRY(down_of(cd, s));
+      int32_t* pn;
+      PCC_TRY(nbr27_of(cd, s->down, &pn));
+      PCC_TRY(pcc_derive_map_down(cd->ctx, pn, s->down->n, s->nbr8, s->parent_of, s->keys, s->n,
+                                  3 * log2i(s->stride), nbr));
+    } else {
+      PCC_TRY(pcc_build_map(cd->ctx, s->keys, s->n, s->stride, nbr));
+    }
+    s->nbr27 = nbr;
+  }
+  *out = s->nbr27;
+  return PCC_OK;
+}
+
+// ---------------------------------------------------------------- layers (model.py)
+int wb(pcc_codec* cd, const std::string& name, const float** w, const float** b, const Tensor** wt) {
+  const Tensor* tw = find(cd, name + ".weight");
+  if (!tw) return PCC_E_ARG;
+  *w = cd->dev[name + ".weight"];
+  *b = cd->dev[name + ".bias"];
+  *wt = tw;
+  return PCC_OK;
+}
+
+int conv3(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat* y) {
+  const float *w, *b;
+  const Tensor* tw;
+  PCC_TRY(wb(cd, name, &w, &b, &tw));
+  const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
+  int32_t* nbr;
+  PCC_TRY(nbr27_of(cd, x.cs, &nbr));
+  CODEC_ALLOC(o, float, std::max<int64_t>(x.cs->n, 1) * cout);
+  PCC_TRY(pcc_sparse_conv(cd->ctx, x.f, x.cs->n, nbr, 27, x.cs->n, x.cs->n, w, b, cin, cout, relu, o));
+  *y = {x.cs, o, cout};
+  return PCC_OK;
+}
+
+int down2(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat* y) {
+  const float *w, *b;
+  const Tensor* tw;
+  PCC_TRY(wb(cd, name, &w, &b, &tw));
+  const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
+  PCC_TRY(down_of(cd, x.cs));
+  CS* p = x.cs->down;
+  CODEC_ALLOC(o, float, std::max<int64_t>(p->n, 1) * cout);
+  PCC_TRY(pcc_sparse_conv(cd->ctx, x.f, x.cs->n, x.cs->nbr8, 8, p->n, p->n, w, b, cin, cout, relu, o));
+  *y = {p, o, cout};
+  return PCC_OK;
+}
+
+int up2(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat* y) {
+  const float *w, *b;
+  const Tensor* tw;
+  PCC_TRY(wb(cd, name, &w, &b, &tw));
+  const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
+  CS* c;
+  PCC_TRY(up_of(cd, x.cs, &c));
+  CODEC_ALLOC(o, float, std::max<int64_t>(c->n, 1) * cout);
+  PCC_TRY(pcc_convT_gen(cd->ctx, x.f, x.cs->n, w, b, cin, cout, relu, o));
+  *y = {c, o, cout};
+  return PCC_OK;
+}
+
+// canonical-order view of a set (utils.sort_coordset / sort_tensor): coordinates [n,4] in the
+// reference's sort order and the permutation canonical position -> row
+struct View {
+  int32_t* coords = nullptr;
+  uint32_t* perm = nullptr;
+  int64_t n = 0;
+};
+
+int view_of(pcc_codec* cd, CS* s, View* v) {
+  const int64_t cap = std::max<int64_t>(s->n, 1);
+  CODEC_ALLOC(c, int32_t, 4 * cap);
+  CODEC_ALLOC(perm, uint32_t, cap);
+  CODEC_ALLOC(cs, int32_t, 4 * cap);
+  if (s->n > 0) {
+    PCC_TRY(pcc_keys_to_coords(cd->ctx, s->keys, s->n, c));
+    PCC_TRY(pcc_sort_coords(cd->ctx, c, s->n, perm));
+    PCC_TRY(pcc_gather_rows(cd->ctx, c, perm, s->n, 16, cs));
+  }
+  *v = {cs, perm, s->n};
+  return PCC_OK;
+}
+
+// rows given in canonical order -> rows of the (Morton-ordered) tensor (utils.sparse_from_rows)
+int rows_to_tensor(pcc_codec* cd, const View& v, const float* rows, int c, float** out) {
+  CODEC_ALLOC(inv, int32_t, std::max<int64_t>(v.n, 1));
+  CODEC_ALLOC(o, float, std::max<int64_t>(v.n, 1) * c);
+  if (v.n > 0) {
+    PCC_TRY(pcc_inverse_rows(cd->ctx, v.perm, v.n, v.n, inv));
+    PCC_TRY(pcc_gather_rows(cd->ctx, rows, (const uint32_t*)inv, v.n, 4 * c, o));
+  }
+  *out = o;
+  return PCC_OK;
+}
+
+// SparseTensor.features_at_coordinates: exact-lattice lookup, zeros where absent
+int features_at(pcc_codec* cd, const Feat& x, const int32_t* qcoords, int64_t m, float** out) {
+  const int64_t cap = std::max<int64_t>(m, 1);
+  CODEC_ALLOC(qkeys, uint64_t, cap);
+  CODEC_ALLOC(flag, int32_t, 1);
+  CODEC_ALLOC(rows, int32_t, cap);
+  CODEC_ALLOC(o, float, cap * x.c);
+  if (m > 0) {
+    PCC_HIP(hipMemsetAsync(flag, 0, 4, cd->ctx->stream));
+    PCC_TRY(pcc_morton_keys(cd->ctx, qcoords, m, qkeys, flag));
+    PCC_TRY(pcc_lookup(cd->ctx, x.cs->keys, x.cs->n, qkeys, m, rows));
+    PCC_TRY(pcc_gather_rows_or_zero(cd->ctx, x.f, rows, m, x.c, o));
+  }
+  *out = o;
+  return PCC_OK;
+}
+
+// scale_nn(q) + eps on the host in float32 with the operation order of model.py ScaleNN
+int scale_row(pcc_codec* cd, double qg, double qa, float* out /*[c_y]*/) {
+  const Tensor *w0 = find(cd, "scale_nn.l0.weight"), *b0 = find(cd, "scale_nn.l0.bias");
+  const Tensor *w1 = find(cd, "scale_nn.l1.weight"), *b1 = find(cd, "scale_nn.l1.bias");
+  const Tensor* eps = find(cd, "entropy_model.eps");
+  if (!w0 || !b0 || !w1 || !b1 || !eps) return PCC_E_ARG;
+  const int hid = (int)w0->dims[1], co = (int)w1->dims[1];
+  const float q[2] = {(float)qg, (float)qa};
+  std::vector<float> h(b0->f32(), b0->f32() + hid);
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < hid; ++j) {
+      const float prod = q[i] * w0->f32()[i * hid + j];
+      h[j] = h[j] + prod;
+    }
+  for (int j = 0; j < hid; ++j) h[j] = std::max(h[j], 0.0f);
+  std::vector<float> o(b1->f32(), b1->f32() + co);
+  for (int i = 0; i < hid; ++i)
+    for (int j = 0; j < co; ++j) {
+      const float prod = h[i] * w1->f32()[i * co + j];
+      o[j] = o[j] + prod;
+    }
+  const float e = eps->f32()[0];
+  for (int j = 0; j < co; ++j) {
+    const float s = 0.5f + fabsf(o[j]);
+    out[j] = s + e;
+  }
+  return PCC_OK;
+}
+
+int h_s(pcc_codec* cd, const Feat& z_hat, Feat* gp) {
+  Feat a, b;
+  PCC_TRY(up2(cd, "h_s.up0", z_hat, 1, &a));
+  PCC_TRY(up2(cd, "h_s.up1", a, 1, &b));
+  return conv3(cd, "h_s.conv0", b, 0, gp);
+}
+
+// ---------------------------------------------------------------- geometry slot (utils.py)
+void octree_root(uint64_t first, uint64_t last, int key_shift, int* depth, int32_t origin[3]) {
+  const uint64_t mask48 = ((uint64_t)1 << 48) - 1;
+  const uint64_t a = (first & mask48) >> key_shift, b = (last & mask48) >> key_shift;
+  const uint64_t diff = a ^ b;
+  int d = 1;
+  if (diff) d = (63 - __builtin_clzll(diff)) / 3 + 1;
+  const uint64_t corner = (a >> (3 * d)) << (3 * d);
+  const int bias = 32768 >> (key_shift / 3);
+  auto compact = [](uint64_t v) {
+    int r = 0;
+    for (int i = 0; i < 16; ++i) r |= (int)((v >> (3 * i)) & 1) << i;
+    return r;
+  };
+  *depth = d;
+  origin[0] = compact(corner >> 2) - bias;
+  origin[1] = compact(corner >> 1) - bias;
+  origin[2] = compact(corner) - bias;
+}
+
+void put_be32(std::vector<uint8_t>& v, int32_t x) {
+  const uint32_t u = (uint32_t)x;
+  v.push_back((uint8_t)(u >> 24));
+  v.push_back((uint8_t)(u >> 16));
+  v.push_back((uint8_t)(u >> 8));
+  v.push_back((uint8_t)u);
+}
+void put_be_f64(std::vector<uint8_t>& v, double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  for (int i = 7; i >= 0; --i) v.push_back((uint8_t)(u >> (8 * i)));
+}
+
+struct Reader {
+  const uint8_t* p;
+  int64_t len, pos = 0;
+  bool bad = false;
+  int32_t be32() {
+    if (pos + 4 > len) { bad = true; return 0; }
+    const uint32_t u = ((uint32_t)p[pos] << 24) | ((uint32_t)p[pos + 1] << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
+    pos += 4;
+    return (int32_t)u;
+  }
+  double be_f64() {
+    if (pos + 8 > len) { bad = true; return 0; }
+    uint64_t u = 0;
+    for (int i = 0; i < 8; ++i) u = (u << 8) | p[pos + i];
+    pos += 8;
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+  }
+  const uint8_t* bytes(int64_t n) {
+    if (n < 0 || pos + n > len) { bad = true; return nullptr; }
+    const uint8_t* r = p + pos;
+    pos += n;
+    return r;
+  }
+};
+
+int rans_encode_grow(const int32_t* sym, const int32_t* idx, int64_t n, const Tensor* cdf, const Tensor* len,
+                     const Tensor* off, std::vector<uint8_t>* out) {
+  int64_t cap = 2 * n + 4096, got = 0;
+  int rc = PCC_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    out->resize((size_t)cap);
+    rc = pcc_rans_encode(sym, idx, n, cdf->i32(), (int)cdf->dims[1], len->i32(), off->i32(), (int)cdf->dims[0],
+                         out->data(), cap, &got);
+    if (rc != PCC_E_NOMEM) break;
+    cap = 48 * n + 4096;
+  }
+  if (rc == PCC_OK) out->resize((size_t)got);
+  return rc;
+}
+
+}  // namespace
+
+// ======================================================================== C-ABI
+
+extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device, void* stream) {
+  if (!h_ckpt || n < 8 || memcmp(h_ckpt, "PCCW", 4) != 0) {
+    pcc_set_error("pcc_codec_create: not a PCCW checkpoint blob");
+    return nullptr;
+  }
+  pcc_ctx* ctx = pcc_create(device, stream);
+  if (!ctx) return nullptr;
+  pcc_codec* cd = new pcc_codec();
+  cd->ctx = ctx;
+  cd->device = device;
+  cd->blob.assign((const uint8_t*)h_ckpt, (const uint8_t*)h_ckpt + n);
+  const uint8_t* p = cd->blob.data();
+  size_t pos = 4;
+  auto fail = [&](const char* why) -> pcc_codec* {
+    pcc_set_error("pcc_codec_create: malformed checkpoint (%s)", why);
+    pcc_destroy(cd->ctx);
+    delete cd;
+    return nullptr;
+  };
+  uint32_t count;
+  memcpy(&count, p + pos, 4);
+  pos += 4;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (pos + 2 > n) return fail("truncated");
+    uint16_t nl;
+    memcpy(&nl, p + pos, 2);
+    pos += 2;
+    if (pos + nl + 2 > n) return fail("truncated name");
+    std::string name((const char*)p + pos, nl);
+    pos += nl;
+    Tensor t;
+    t.dtype = p[pos];
+    const int nd = p[pos + 1];
+    pos += 2;
+    if (pos + 4 * (size_t)nd + 8 > n) return fail("truncated dims");
+    for (int d = 0; d < nd; ++d) {
+      uint32_t v;
+      memcpy(&v, p + pos, 4);
+      pos += 4;
+      t.dims.push_back(v);
+    }
+    uint64_t nb;
+    memcpy(&nb, p + pos, 8);
+    pos += 8;
+    pos = (pos + 7) & ~(size_t)7;
+    if (pos + nb > n || nb != (uint64_t)t.numel() * 4) return fail("bad tensor size");
+    t.data = p + pos;
+    t.nbytes = nb;
+    pos = (pos + nb + 7) & ~(size_t)7;
+    cd->t[name] = t;
+  }
+  // weights, biases and the small float tables the kernels read go to HBM once
+  for (auto& kv : cd->t) {
+    const std::string& k = kv.first;
+    const bool is_wb = (k.size() > 7 && k.compare(k.size() - 7, 7, ".weight") == 0) ||
+                       (k.size() > 5 && k.compare(k.size() - 5, 5, ".bias") == 0);
+    const bool is_tab = k == "entropy_bottleneck.medians" || k == "gaussian_conditional.scale_table";
+    if ((!is_wb && !is_tab) || k.compare(0, 8, "scale_nn") == 0 || kv.second.dtype != 0) continue;
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, std::max<size_t>(kv.second.nbytes, 4)) != hipSuccess ||
+        hipMemcpy(d, kv.second.data, kv.second.nbytes, hipMemcpyHostToDevice) != hipSuccess) {
+      pcc_set_error("pcc_codec_create: upload of '%s' failed", k.c_str());
+      pcc_destroy(cd->ctx);
+      delete cd;
+      return nullptr;
+    }
+    cd->dev[k] = d;
+  }
+  static const char* need[] = {"g_a.conv0.weight", "g_a.conv3.weight", "h_a.conv0.weight", "h_s.conv0.weight",
+                               "g_s.color.weight", "entropy_bottleneck.quantized_cdf",
+                               "gaussian_conditional.quantized_cdf", "gaussian_conditional.scale_table",
+                               "entropy_bottleneck.medians", "entropy_model.offsets_ab", "entropy_model.eps"};
+  for (const char* k : need)
+    if (!cd->t.count(k)) {
+      pcc_set_error("pcc_codec_create: checkpoint has no tensor '%s'", k);
+      for (auto& kv : cd->dev) (void)hipFree(kv.second);
+      pcc_destroy(cd->ctx);
+      delete cd;
+      return nullptr;
+    }
+  cd->c_y = (int)cd->t["g_a.conv3.weight"].dims[2];
+  cd->c_z = (int)cd->t["entropy_bottleneck.medians"].dims[0];
+  return cd;
+}
+
+extern "C" void pcc_codec_destroy(pcc_codec* cd) {
+  if (!cd) return;
+  if (cd->ctx) (void)pcc_sync(cd->ctx);
+  for (auto& kv : cd->dev) (void)hipFree(kv.second);
+  cd->pool.release();
+  for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec})
+    p->release();
+  pcc_destroy(cd->ctx);
+  delete cd;
+}
+
+extern "C" pcc_ctx* pcc_codec_ctx(pcc_codec* cd) { return cd ? cd->ctx : nullptr; }
+
+// ---------------------------------------------------------------------------- encode
+extern "C" int pcc_encode_gop(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n,
+                              int n_frames, const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k,
+                              double* h_stage_s) {
+  PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_encode_gop: null codec");
+  PCC_REQUIRE(n > 0 && d_coords && d_feats && n_frames >= 1 && n_frames <= 65535 && h_q && n_q >= 1 &&
+                  n_q <= 64 && h_out,
+              PCC_E_ARG, "pcc_encode_gop: bad argument (n=%lld frames=%d q=%d)", (long long)n, n_frames, n_q);
+  pcc_ctx* ctx = cd->ctx;
+  hipStream_t st = ctx->stream;
+  PCC_HIP(hipSetDevice(cd->device));
+  PCC_TRY(pcc_sync(ctx));  // the previous call's tensors are dead from here on
+  cd->pool.reset();
+  cd->sets.clear();
+  cd->out.assign((size_t)n_q, {});
+  const int cy = cd->c_y, cz = cd->c_z;
+  double ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double t0 = now_s();
+
+  // ---- unpack_batch: SparseTensor(coordinates, features) -> Morton-sorted rows
+  Feat x;
+  {
+    CODEC_ALLOC(keys, uint64_t, n);
+    CODEC_ALLOC(flag, int32_t, 1);
+    CODEC_ALLOC(perm, uint32_t, n);
+    CODEC_ALLOC(f, float, 4 * n);
+    PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
+    PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
+    PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
+    PCC_TRY(cd->pin_flag.ensure(64));
+    PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
+    int dup = 0;
+    PCC_TRY(pcc_check_unique(ctx, keys, n, &dup));
+    PCC_HIP(hipStreamSynchronize(st));
+    PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE,
+                "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0,65534]");
+    PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_encode_gop: duplicate coordinates");
+    PCC_TRY(pcc_gather_rows(ctx, d_feats, perm, n, 16, f));
+    x = {new_set(cd, keys, n, 1, n_frames), f, 4};
+  }
+
+  // ---- step 1: analysis g_a + canonical order of y (codec_pipeline.py:270-281)
+  std::vector<std::vector<int64_t>> counts(3);
+  Feat h = x, y;
+  for (int j = 0; j < 3; ++j) {
+    const std::vector<int64_t>* offs;
+    PCC_TRY(offsets_of(cd, h.cs, &offs));
+    for (int f = 0; f < n_frames; ++f) counts[j].push_back((*offs)[f + 1] - (*offs)[f]);
+    Feat a, b;
+    PCC_TRY(conv3(cd, "g_a.conv" + std::to_string(j), h, 1, &a));
+    PCC_TRY(down2(cd, "g_a.down" + std::to_string(j), a, 1, &b));
+    h = b;
+  }
+  PCC_TRY(conv3(cd, "g_a.conv3", h, 0, &y));
+  // k[scale][frame]: strides 4, 2, 1 (coarse -> fine)
+  const std::vector<int64_t>* kk[3] = {&counts[2], &counts[1], &counts[0]};
+  if (h_k)
+    for (int s = 0; s < 3; ++s)
+      for (int f = 0; f < n_frames; ++f) h_k[s * n_frames + f] = (*kk[s])[f];
+  const int64_t ny = y.cs->n;
+  View yv;
+  PCC_TRY(view_of(cd, y.cs, &yv));
+  CODEC_ALLOC(ys_f, float, std::max<int64_t>(ny, 1) * cy);
+  if (ny > 0) PCC_TRY(pcc_gather_rows(ctx, y.f, yv.perm, ny, 4 * cy, ys_f));
+  const std::vector<int64_t>* yoffs;
+  PCC_TRY(offsets_of(cd, y.cs, &yoffs));
+  PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 8));
+  if (ny > 0) PCC_HIP(hipMemcpyAsync(cd->pin_keys.p, y.cs->keys, (size_t)ny * 8, hipMemcpyDeviceToHost, st));
+  PCC_HIP(hipStreamSynchronize(st));
+  const uint64_t* ykeys_h = (const uint64_t*)cd->pin_keys.p;
+  ts[0] = now_s() - t0;
+
+  // ---- step 6 (device half): octree occupancy bytes of every frame (codec_pipeline.py:441-462)
+  t0 = now_s();
+  struct FrameGeo {
+    int64_t n, occ_off, occ_len;
+    int depth;
+    int32_t origin[3];
+    std::vector<int64_t> level_n;
+  };
+  std::vector<FrameGeo> geo((size_t)n_frames);
+  {
+    int64_t cap_total = 0;
+    for (int f = 0; f < n_frames; ++f) {
+      FrameGeo& g = geo[f];
+      g.n = (*yoffs)[f + 1] - (*yoffs)[f];
+      g.depth = 0;
+      g.occ_off = cap_total;
+      g.occ_len = 0;
+      g.origin[0] = g.origin[1] = g.origin[2] = 0;
+      if (g.n > 0) {
+        octree_root(ykeys_h[(*yoffs)[f]], ykeys_h[(*yoffs)[f + 1] - 1], 9, &g.depth, g.origin);
+        cap_total += g.n * g.depth;
+      }
+    }
+    CODEC_ALLOC(occ, uint8_t, std::max<int64_t>(cap_total, 1));
+    PCC_TRY(cd->pin_occ.ensure((size_t)std::max<int64_t>(cap_total, 1)));
+    for (int f = 0; f < n_frames; ++f) {
+      FrameGeo& g = geo[f];
+      if (g.n == 0) continue;
+      g.level_n.assign((size_t)g.depth, 0);
+      PCC_TRY(pcc_octree_levels(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, occ + g.occ_off, g.n * g.depth,
+                                g.level_n.data()));
+      for (int64_t v : g.level_n) g.occ_len += v;
+      PCC_HIP(hipMemcpyAsync(cd->pin_occ.p + g.occ_off, occ + g.occ_off, (size_t)g.occ_len, hipMemcpyDeviceToHost, st));
+    }
+  }
+  ts[4] = now_s() - t0;
+
+  // ---- step 2: hyper analysis h_a
+  t0 = now_s();
+  Feat z;
+  {
+    Feat a, b;
+    PCC_TRY(conv3(cd, "h_a.conv0", y, 1, &a));
+    PCC_TRY(down2(cd, "h_a.down0", a, 1, &b));
+    PCC_TRY(down2(cd, "h_a.down1", b, 0, &z));
+  }
+  ts[1] = now_s() - t0;
+
+  // ---- step 3: factorized model over the canonically sorted z; z_hat formed on the device
+  t0 = now_s();
+  const int64_t nz = z.cs->n;
+  View zv;
+  PCC_TRY(view_of(cd, z.cs, &zv));
+  Feat z_hat;
+  {
+    CODEC_ALLOC(zs_f, float, std::max<int64_t>(nz, 1) * cz);
+    CODEC_ALLOC(zsym, int32_t, std::max<int64_t>(nz, 1) * cz);
+    CODEC_ALLOC(zhat_rows, float, std::max<int64_t>(nz, 1) * cz);
+    PCC_TRY(cd->pin_zsym.ensure((size_t)std::max<int64_t>(nz, 1) * cz * 4));
+    if (nz > 0) {
+      PCC_TRY(pcc_gather_rows(ctx, z.f, zv.perm, nz, 4 * cz, zs_f));
+      PCC_TRY(pcc_factorized_quant(ctx, zs_f, nz, cz, cd->dev["entropy_bottleneck.medians"], zsym, zhat_rows));
+      PCC_HIP(hipMemcpyAsync(cd->pin_zsym.p, zsym, (size_t)nz * cz * 4, hipMemcpyDeviceToHost, st));
+    }
+    float* zf;
+    PCC_TRY(rows_to_tensor(cd, zv, zhat_rows, cz, &zf));
+    z_hat = {z.cs, zf, cz};
+  }
+  hipEvent_t ev_host;
+  PCC_HIP(hipEventCreateWithFlags(&ev_host, hipEventDisableTiming));
+  PCC_HIP(hipEventRecord(ev_host, st));
+  // helper thread: geometry blobs + z string, neither feeds the GPU path
+  std::vector<std::vector<uint8_t>> blobs((size_t)n_frames);
+  std::vector<uint8_t> z_string;
+  int helper_rc = PCC_OK;
+  std::string helper_err;
+  double helper_geo_s = 0, helper_z_s = 0;
+  const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
+               *eb_off = find(cd, "entropy_bottleneck.offset");
+  PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_encode_gop: entropy_bottleneck tables missing");
+  std::thread helper([&]() {
+    (void)hipSetDevice(cd->device);
+    if (hipEventSynchronize(ev_host) != hipSuccess) {
+      helper_rc = PCC_E_HIP;
+      helper_err = "hipEventSynchronize failed";
+      return;
+    }
+    double t = now_s();
+    for (int f = 0; f < n_frames && helper_rc == PCC_OK; ++f) {
+      const FrameGeo& g = geo[f];
+      const int64_t cap = 64 + 2 * g.occ_len + 16;
+      blobs[f].resize((size_t)cap);
+      int64_t len = 0;
+      const int64_t zero = 0;
+      helper_rc = pcc_octree_pack(g.n ? cd->pin_occ.p + g.occ_off : nullptr, g.n ? g.level_n.data() : &zero, g.depth,
+                                  g.n, g.origin, blobs[f].data(), cap, &len);
+      if (helper_rc == PCC_OK) blobs[f].resize((size_t)len);
+    }
+    helper_geo_s = now_s() - t;
+    t = now_s();
+    if (helper_rc == PCC_OK) {
+      std::vector<int32_t> idx((size_t)nz * cz);
+      for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz, idx.begin() + (size_t)(c + 1) * nz, c);
+      helper_rc = rans_encode_grow((const int32_t*)cd->pin_zsym.p, idx.data(), nz * cz, eb_cdf, eb_len, eb_off, &z_string);
+    }
+    helper_z_s = now_s() - t;
+    if (helper_rc != PCC_OK) helper_err = pcc_last_error();
+  });
+  struct Joiner {  // the helper references locals: never leave this frame with it running
+    std::thread& t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joiner{helper};
+  ts[2] = now_s() - t0;
+
+  // ---- step 4: hyper synthesis h_s -> (scales_hat | means_hat) at stride 8
+  t0 = now_s();
+  Feat gp;
+  PCC_TRY(h_s(cd, z_hat, &gp));
+  ts[3] = now_s() - t0;
+
+  // ---- step 5: all Q quality streams at once (codec_pipeline.py:397-437)
+  t0 = now_s();
+  std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);
+  {
+    float* params;
+    PCC_TRY(features_at(cd, gp, yv.coords, ny, &params));
+    std::vector<float> scale_h((size_t)n_q * cy);
+    for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &scale_h[(size_t)q * cy]));
+    CODEC_ALLOC(scale_d, float, n_q * cy);
+    PCC_HIP(hipMemcpyAsync(scale_d, scale_h.data(), scale_h.size() * 4, hipMemcpyHostToDevice, st));
+    const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
+    const Tensor *gc_cdf = find(cd, "gaussian_conditional.quantized_cdf"), *gc_len = find(cd, "gaussian_conditional.cdf_length"),
+                 *gc_off = find(cd, "gaussian_conditional.offset");
+    PCC_REQUIRE(tab && gc_cdf && gc_len && gc_off, PCC_E_ARG, "pcc_encode_gop: gaussian_conditional tables missing");
+    const int ntab = (int)tab->dims[0];
+    const int64_t per = (int64_t)cy * ny, tot = per * n_q;
+    CODEC_ALLOC(sym16, int16_t, std::max<int64_t>(tot, 1));
+    CODEC_ALLOC(idx8, uint8_t, std::max<int64_t>(tot, 1));
+    CODEC_ALLOC(flag, int32_t, 1);
+    PCC_TRY(cd->pin_ysym.ensure((size_t)std::max<int64_t>(tot, 1) * 4));
+    PCC_TRY(cd->pin_yidx.ensure((size_t)std::max<int64_t>(tot, 1) * 4));
+    PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
+    if (ny > 0) {
+      PCC_TRY(pcc_gaussian_quant16(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
+                                   ntab, sym16, idx8, flag));
+      PCC_HIP(hipMemcpyAsync(cd->pin_ysym.p, sym16, (size_t)tot * 2, hipMemcpyDeviceToHost, st));
+      PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p, idx8, (size_t)tot, hipMemcpyDeviceToHost, st));
+    }
+    PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
+    PCC_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> lens((size_t)n_q, 0);
+    std::vector<uint8_t> stage;
+    int rc = PCC_OK;
+    int64_t cap = 2 * per + 4096;
+    if (*(int32_t*)cd->pin_flag.p == 0) {
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        stage.resize((size_t)cap * n_q);
+        rc = pcc_rans_encode_multi16((const int16_t*)cd->pin_ysym.p, cd->pin_yidx.p, per, n_q, gc_cdf->i32(),
+                                     (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0],
+                                     stage.data(), cap, lens.data());
+        if (rc != PCC_E_NOMEM) break;
+        cap = 48 * per + 4096;
+      }
+    } else {  // a symbol outside int16: the generic int32 form
+      CODEC_ALLOC(sym32, int32_t, std::max<int64_t>(tot, 1));
+      CODEC_ALLOC(idx32, int32_t, std::max<int64_t>(tot, 1));
+      PCC_TRY(pcc_gaussian_quant(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
+                                 ntab, sym32, idx32));
+      PCC_HIP(hipMemcpyAsync(cd->pin_ysym.p, sym32, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
+      PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p, idx32, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
+      PCC_HIP(hipStreamSynchronize(st));
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        stage.resize((size_t)cap * n_q);
+        rc = pcc_rans_encode_multi((const int32_t*)cd->pin_ysym.p, (const int32_t*)cd->pin_yidx.p, per, n_q,
+                                   gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(),
+                                   (int)gc_cdf->dims[0], stage.data(), cap, lens.data());
+        if (rc != PCC_E_NOMEM) break;
+        cap = 48 * per + 4096;
+      }
+    }
+    PCC_TRY(rc);
+    for (int q = 0; q < n_q; ++q)
+      y_strings[q].assign(stage.begin() + (size_t)q * cap, stage.begin() + (size_t)q * cap + (size_t)lens[q]);
+  }
+  ts[5] = now_s() - t0;
+
+  helper.join();
+  (void)hipEventDestroy(ev_host);
+  if (helper_rc != PCC_OK) {
+    pcc_set_error("pcc_encode_gop (host coders): %s", helper_err.c_str());
+    return helper_rc;
+  }
+  ts[4] += helper_geo_s;
+  ts[2] += helper_z_s;
+
+  // ---- step 7: containers, field for field the reference writer (codec_pipeline.py:464-517)
+  t0 = now_s();
+  for (int q = 0; q < n_q; ++q) {
+    std::vector<uint8_t>& o = cd->out[q];
+    o.clear();
+    put_be32(o, n_frames);
+    put_be_f64(o, h_q[2 * q]);
+    put_be_f64(o, h_q[2 * q + 1]);
+    put_be32(o, (int32_t)ny);
+    put_be32(o, (int32_t)nz);
+    put_be32(o, (int32_t)y_strings[q].size());
+    put_be32(o, (int32_t)z_string.size());
+    o.insert(o.end(), y_strings[q].begin(), y_strings[q].end());
+    o.insert(o.end(), z_string.begin(), z_string.end());
+    for (int f = 0; f < n_frames; ++f) {
+      put_be32(o, (int32_t)blobs[f].size());
+      for (int s = 0; s < 3; ++s) put_be32(o, (int32_t)(*kk[s])[f]);
+      o.insert(o.end(), blobs[f].begin(), blobs[f].end());
+    }
+    h_out[q].data = o.data();
+    h_out[q].len = (int64_t)o.size();
+  }
+  ts[6] = now_s() - t0;
+  if (h_stage_s) memcpy(h_stage_s, ts, 7 * sizeof(double));
+  return PCC_OK;
+}
+
+// ---------------------------------------------------------------------------- decode
+extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_cloud_info* h_info,
+                              double* h_stage_s) {
+  PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_decode_gop: null codec");
+  PCC_REQUIRE(h_in && len >= 36 && h_info, PCC_E_STREAM, "pcc_decode_gop: container shorter than its header");
+  pcc_ctx* ctx = cd->ctx;
+  hipStream_t st = ctx->stream;
+  PCC_HIP(hipSetDevice(cd->device));
+  PCC_TRY(pcc_sync(ctx));
+  cd->pool.reset();
+  cd->sets.clear();
+  cd->rec_n = 0;
+  cd->rec_offsets.clear();
+  const int cy = cd->c_y, cz = cd->c_z;
+  double ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- step 1: container (codec_parallel.py:173-216)
+  double t0 = now_s();
+  Reader r{h_in, len};
+  const int32_t n_frames = r.be32();
+  const double qg = r.be_f64(), qa = r.be_f64();
+  const int32_t ny_hdr = r.be32(), nz_hdr = r.be32(), ylen = r.be32(), zlen = r.be32();
+  const uint8_t* ystr = r.bytes(ylen);
+  const uint8_t* zstr = r.bytes(zlen);
+  PCC_REQUIRE(!r.bad && n_frames >= 0 && n_frames <= 65535 && ny_hdr >= 0 && nz_hdr >= 0, PCC_E_STREAM,
+              "pcc_decode_gop: truncated container");
+  struct Slot {
+    const uint8_t* p;
+    int32_t len;
+  };
+  std::vector<Slot> slots((size_t)n_frames);
+  std::vector<int64_t> ks[3];
+  for (int f = 0; f < n_frames; ++f) {
+    const int32_t pl = r.be32();
+    for (int s = 0; s < 3; ++s) ks[s].push_back(r.be32());
+    slots[f] = {r.bytes(pl), pl};
+    PCC_REQUIRE(!r.bad, PCC_E_STREAM, "pcc_decode_gop: truncated container");
+  }
+  ts[0] = now_s() - t0;
+
+  // z string: nothing from the GPU is needed, decode it on a helper thread right away
+  const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
+               *eb_off = find(cd, "entropy_bottleneck.offset");
+  PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_decode_gop: entropy_bottleneck tables missing");
+  std::vector<int32_t> zsym((size_t)std::max<int64_t>((int64_t)nz_hdr * cz, 1));
+  int z_rc = PCC_OK;
+  std::string z_err;
+  std::thread helper([&]() {
+    if (nz_hdr == 0) return;
+    std::vector<int32_t> idx((size_t)nz_hdr * cz);
+    for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz_hdr, idx.begin() + (size_t)(c + 1) * nz_hdr, c);
+    z_rc = pcc_rans_decode(zstr, zlen, idx.data(), (int64_t)nz_hdr * cz, eb_cdf->i32(), (int)eb_cdf->dims[1],
+                           eb_len->i32(), eb_off->i32(), (int)eb_cdf->dims[0], zsym.data());
+    if (z_rc != PCC_OK) z_err = pcc_last_error();
+  });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joiner{helper};
+
+  // ---- step 2: latent coordinates of every frame (codec_parallel.py:266-289)
+  t0 = now_s();
+  int64_t ny = 0;
+  std::vector<int64_t> fn((size_t)n_frames, 0);
+  for (int f = 0; f < n_frames; ++f) {
+    int depth;
+    int32_t org[3];
+    PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, &fn[f], &depth, org));
+    ny += fn[f];
+  }
+  PCC_REQUIRE(ny == ny_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_y=%d, geometry gives %lld", ny_hdr,
+              (long long)ny);
+  PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
+  int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
+  int n_batch = 0;
+  {
+    std::vector<int32_t> pts;
+    int64_t row = 0;
+    for (int f = 0; f < n_frames; ++f) {
+      if (fn[f] == 0) continue;
+      pts.resize((size_t)fn[f] * 3);
+      PCC_TRY(pcc_octree_unpack(slots[f].p, slots[f].len, pts.data(), fn[f]));
+      for (int64_t i = 0; i < fn[f]; ++i, ++row) {
+        yc_h[4 * row] = f;
+        yc_h[4 * row + 1] = pts[3 * i] * 8;
+        yc_h[4 * row + 2] = pts[3 * i + 1] * 8;
+        yc_h[4 * row + 3] = pts[3 * i + 2] * 8;
+      }
+      n_batch = f + 1;
+    }
+  }
+  ts[1] = now_s() - t0;
+
+  // ---- step 3: z coordinates re-derived from the y coordinates, z decoded (codec_parallel.py:291-318)
+  t0 = now_s();
+  CS* ycs;
+  {
+    CODEC_ALLOC(yc, int32_t, 4 * std::max<int64_t>(ny, 1));
+    CODEC_ALLOC(keys, uint64_t, std::max<int64_t>(ny, 1));
+    CODEC_ALLOC(flag, int32_t, 1);
+    CODEC_ALLOC(perm, uint32_t, std::max<int64_t>(ny, 1));
+    if (ny > 0) {
+      PCC_HIP(hipMemcpyAsync(yc, yc_h, (size_t)ny * 16, hipMemcpyHostToDevice, st));
+      PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
+      PCC_TRY(pcc_morton_keys(ctx, yc, ny, keys, flag));
+      PCC_TRY(pcc_sort_pairs(ctx, keys, perm, ny, 0));
+      PCC_TRY(cd->pin_flag.ensure(64));
+      PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
+      int dup = 0;
+      PCC_TRY(pcc_check_unique(ctx, keys, ny, &dup));
+      PCC_HIP(hipStreamSynchronize(st));
+      PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE, "pcc_decode_gop: decoded coordinate out of range");
+      PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_decode_gop: duplicate latent coordinates");
+    }
+    ycs = new_set(cd, keys, ny, 8, std::max(n_batch, 1));
+  }
+  PCC_TRY(down_of(cd, ycs));
+  PCC_TRY(down_of(cd, ycs->down));
+  CS* zcs = ycs->down->down;
+  View zv;
+  PCC_TRY(view_of(cd, zcs, &zv));
+  PCC_REQUIRE(zcs->n == nz_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_z=%d, coordinates give %lld", nz_hdr,
+              (long long)zcs->n);
+  helper.join();
+  if (z_rc != PCC_OK) {
+    pcc_set_error("pcc_decode_gop (z stream): %s", z_err.c_str());
+    return z_rc;
+  }
+  Feat z_hat;
+  {
+    const int64_t nz = zcs->n;
+    CODEC_ALLOC(zsym_d, int32_t, std::max<int64_t>(nz, 1) * cz);
+    CODEC_ALLOC(rows, float, std::max<int64_t>(nz, 1) * cz);
+    if (nz > 0) {
+      PCC_TRY(cd->pin_zsym.ensure((size_t)nz * cz * 4));
+      memcpy(cd->pin_zsym.p, zsym.data(), (size_t)nz * cz * 4);
+      PCC_HIP(hipMemcpyAsync(zsym_d, cd->pin_zsym.p, (size_t)nz * cz * 4, hipMemcpyHostToDevice, st));
+      PCC_TRY(pcc_factorized_dequant(ctx, zsym_d, nz, cz, cd->dev["entropy_bottleneck.medians"], rows));
+    }
+    float* zf;
+    PCC_TRY(rows_to_tensor(cd, zv, rows, cz, &zf));
+    z_hat = {zcs, zf, cz};
+  }
+  ts[2] = now_s() - t0;
+
+  // ---- step 4: hyper synthesis
+  t0 = now_s();
+  Feat gp;
+  PCC_TRY(h_s(cd, z_hat, &gp));
+  ts[3] = now_s() - t0;
+
+  // ---- step 5: decode y, de-quantise with offsets (codec_parallel.py:382-419)
+  t0 = now_s();
+  Feat y_hat;
+  {
+    View yv;
+    PCC_TRY(view_of(cd, ycs, &yv));
+    float* params;
+    PCC_TRY(features_at(cd, gp, yv.coords, ny, &params));
+    std::vector<float> scale_h((size_t)cy);
+    PCC_TRY(scale_row(cd, qg, qa, scale_h.data()));
+    CODEC_ALLOC(scale_d, float, cy);
+    PCC_HIP(hipMemcpyAsync(scale_d, scale_h.data(), (size_t)cy * 4, hipMemcpyHostToDevice, st));
+    const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
+    const Tensor *gc_cdf = find(cd, "gaussian_conditional.quantized_cdf"), *gc_len = find(cd, "gaussian_conditional.cdf_length"),
+                 *gc_off = find(cd, "gaussian_conditional.offset");
+    const Tensor* ab = find(cd, "entropy_model.offsets_ab");
+    PCC_REQUIRE(tab && gc_cdf && gc_len && gc_off && ab, PCC_E_ARG, "pcc_decode_gop: gaussian_conditional tables missing");
+    const int64_t tot = (int64_t)cy * ny;
+    CODEC_ALLOC(idx8, uint8_t, std::max<int64_t>(tot, 1));
+    CODEC_ALLOC(sym_d, int32_t, std::max<int64_t>(tot, 1));
+    CODEC_ALLOC(rows, float, std::max<int64_t>(tot, 1));
+    if (ny > 0) {
+      PCC_TRY(pcc_gaussian_indexes8(ctx, params, ny, cy, scale_d, cd->dev["gaussian_conditional.scale_table"],
+                                    (int)tab->dims[0], idx8));
+      PCC_TRY(cd->pin_yidx.ensure((size_t)tot));
+      PCC_TRY(cd->pin_dec.ensure((size_t)tot * 4));
+      PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p, idx8, (size_t)tot, hipMemcpyDeviceToHost, st));
+      PCC_HIP(hipStreamSynchronize(st));
+      PCC_TRY(pcc_rans_decode8(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(),
+                               gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p));
+      PCC_HIP(hipMemcpyAsync(sym_d, cd->pin_dec.p, (size_t)tot * 4, hipMemcpyHostToDevice, st));
+      PCC_TRY(pcc_gaussian_dequant(ctx, sym_d, params, ny, cy, scale_d, tab->f32()[0], ab->f32()[0], ab->f32()[1], rows));
+    }
+    float* yf;
+    PCC_TRY(rows_to_tensor(cd, yv, rows, cy, &yf));
+    y_hat = {ycs, yf, cy};
+  }
+  ts[4] = now_s() - t0;
+
+  // ---- step 6: synthesis g_s with per-frame top-k pruning (codec_parallel.py:465-472)
+  t0 = now_s();
+  Feat h = y_hat;
+  const int nb = h.cs->n_batch;
+  {
+    const std::vector<int64_t>* o0;
+    PCC_TRY(offsets_of(cd, h.cs, &o0));
+  }
+  for (int j = 0; j < 3; ++j) {
+    Feat u;
+    PCC_TRY(up2(cd, "g_s.up" + std::to_string(j), h, 1, &u));
+    const std::string cname = "g_s.conv" + std::to_string(j), oname = "g_s.occ" + std::to_string(j);
+    const float *w, *b, *hw, *hb;
+    const Tensor *tw, *thw;
+    PCC_TRY(wb(cd, cname, &w, &b, &tw));
+    PCC_TRY(wb(cd, oname, &hw, &hb, &thw));
+    const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
+    int32_t* nbr;
+    PCC_TRY(nbr27_of(cd, u.cs, &nbr));
+    const int64_t nu = u.cs->n;
+    CODEC_ALLOC(feats, float, std::max<int64_t>(nu, 1) * cout);
+    CODEC_ALLOC(logits, float, std::max<int64_t>(nu, 1));
+    PCC_TRY(pcc_sparse_conv_head(ctx, u.f, nu, nbr, 27, nu, nu, w, b, cin, cout, 1, feats, hw, hb, logits));
+    const std::vector<int64_t>* offs;
+    PCC_TRY(offsets_of(cd, u.cs, &offs));
+    std::vector<int64_t> kj((size_t)nb), new_offs(1, 0);
+    for (int f = 0; f < nb; ++f) {
+      const int64_t want = f < (int)ks[j].size() ? ks[j][f] : 0;
+      kj[f] = std::max<int64_t>(0, std::min<int64_t>(want, (*offs)[f + 1] - (*offs)[f]));
+      new_offs.push_back(new_offs.back() + kj[f]);
+    }
+    CODEC_ALLOC(keep, uint32_t, std::max<int64_t>(nu, 1));
+    int64_t n_keep = 0;
+    if (nu > 0) PCC_TRY(pcc_topk_prune(ctx, logits, nu, nb, offs->data(), kj.data(), keep, &n_keep));
+    CODEC_ALLOC(pkeys, uint64_t, std::max<int64_t>(n_keep, 1));
+    CODEC_ALLOC(pf, float, std::max<int64_t>(n_keep, 1) * cout);
+    if (n_keep > 0) {
+      PCC_TRY(pcc_gather_rows(ctx, u.cs->keys, keep, n_keep, 8, pkeys));
+      PCC_TRY(pcc_gather_rows(ctx, feats, keep, n_keep, 4 * cout, pf));
+    }
+    CS* ps = new_set(cd, pkeys, n_keep, u.cs->stride, nb);
+    ps->offsets = new_offs;
+    ps->subset_of = u.cs;
+    ps->keep = keep;
+    h = {ps, pf, cout};
+  }
+  {
+    const float *w, *b;
+    const Tensor* tw;
+    PCC_TRY(wb(cd, "g_s.color", &w, &b, &tw));
+    const int64_t nr = h.cs->n;
+    CODEC_ALLOC(rgb, float, std::max<int64_t>(nr, 1) * 3);
+    CODEC_ALLOC(coords, int32_t, std::max<int64_t>(nr, 1) * 4);
+    if (nr > 0) {
+      PCC_TRY(pcc_linear(ctx, h.f, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
+      PCC_TRY(pcc_keys_to_coords(ctx, h.cs->keys, nr, coords));
+    }
+    cd->rec_coords = coords;
+    cd->rec_colors = rgb;
+    cd->rec_n = nr;
+    cd->rec_offsets = h.cs->offsets;
+  }
+  PCC_TRY(pcc_sync(ctx));
+  ts[5] = now_s() - t0;
+
+  h_info->n_points = cd->rec_n;
+  h_info->n_frames = n_frames;
+  h_info->n_offsets = (int32_t)cd->rec_offsets.size();
+  h_info->h_offsets = cd->rec_offsets.data();
+  h_info->d_coords = cd->rec_coords;
+  h_info->d_colors = cd->rec_colors;
+  h_info->q_g = qg;
+  h_info->q_a = qa;
+  if (h_stage_s) memcpy(h_stage_s, ts, 6 * sizeof(double));
+  return PCC_OK;
+}
+
+extern "C" int pcc_decode_fetch(pcc_codec* cd, int32_t* d_coords, float* d_colors) {
+  PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_decode_fetch: null codec");
+  if (cd->rec_n == 0) return PCC_OK;
+  PCC_REQUIRE(cd->rec_coords && cd->rec_colors, PCC_E_ARG, "pcc_decode_fetch: no decoded GOP on this codec");
+  hipStream_t st = cd->ctx->stream;
+  if (d_coords) PCC_HIP(hipMemcpyAsync(d_coords, cd->rec_coords, (size_t)cd->rec_n * 16, hipMemcpyDeviceToDevice, st));
+  if (d_colors) PCC_HIP(hipMemcpyAsync(d_colors, cd->rec_colors, (size_t)cd->rec_n * 12, hipMemcpyDeviceToDevice, st));
+  PCC_HIP(hipStreamSynchronize(st));
+  return PCC_OK;
+}
+
+// ---------------------------------------------------------------------------- geometry slot, one call each
+extern "C" int pcc_octree_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, uint8_t* h_out,
+                                 int64_t cap, int64_t* h_len) {
+  PCC_REQUIRE(ctx && h_out && h_len && n >= 0 && (n == 0 || d_keys), PCC_E_ARG, "pcc_octree_encode: bad argument");
+  const int64_t zero = 0;
+  const int32_t org0[3] = {0, 0, 0};
+  if (n == 0) return pcc_octree_pack(nullptr, &zero, 0, 0, org0, h_out, cap, h_len);
+  uint64_t ends[2];
+  PCC_HIP(hipMemcpyAsync(&ends[0], d_keys, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipMemcpyAsync(&ends[1], d_keys + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCC_HIP(hipStreamSynchronize(ctx->stream));
+  int depth;
+  int32_t origin[3];
+  octree_root(ends[0], ends[1], key_shift, &depth, origin);
+  uint8_t* d_occ = nullptr;
+  PCC_HIP(hipMalloc((void**)&d_occ, (size_t)n * depth));
+  std::vector<int64_t> level_n((size_t)depth, 0);
+  int rc = pcc_octree_levels(ctx, d_keys, n, key_shift, depth, d_occ, n * depth, level_n.data());
+  std::vector<uint8_t> occ;
+  if (rc == PCC_OK) {
+    int64_t tot = 0;
+    for (int64_t v : level_n) tot += v;
+    occ.resize((size_t)std::max<int64_t>(tot, 1));
+    if (hipMemcpy(occ.data(), d_occ, (size_t)tot, hipMemcpyDeviceToHost) != hipSuccess) rc = PCC_E_HIP;
+  }
+  (void)hipFree(d_occ);
+  PCC_TRY(rc);
+  return pcc_octree_pack(occ.data(), level_n.data(), depth, n, origin, h_out, cap, h_len);
+}
+
+extern "C" int pcc_octree_decode(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
+                                 int64_t* h_n_points) {
+  int64_t n = 0;
+  int depth = 0;
+  int32_t org[3];
+  PCC_TRY(pcc_octree_peek(h_in, len, &n, &depth, org));
+  if (h_n_points) *h_n_points = n;
+  if (!h_points || n == 0) return PCC_OK;
+  PCC_REQUIRE(cap_points >= n, PCC_E_NOMEM, "pcc_octree_decode: %lld points, capacity %lld", (long long)n,
+              (long long)cap_points);
+  return pcc_octree_unpack(h_in, len, h_points, cap_points);
+}

@@ -64,10 +64,24 @@ class Runtime:
         self._stream_cm = None
         self._prev = None
 
+    @classmethod
+    def adopt(cls, ctx, stream, device):
+        """Runtime view of a ctx owned by someone else (a pcc_codec): same helpers / profiler,
+        close() leaves the ctx alone"""
+        self = cls.__new__(cls)
+        self.lib = _abi.lib()
+        self.device = device
+        self.stream = stream
+        self.ctx = ctx
+        self._owned = False
+        self._stream_cm = None
+        self._prev = None
+        return self
+
     def close(self):
-        if self.ctx:
+        if self.ctx and getattr(self, "_owned", True):
             self.lib.pcc_destroy(self.ctx)
-            self.ctx = None
+        self.ctx = None
 
     def __del__(self):
         try:

@@ -334,6 +334,78 @@ int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points,
 int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_points,
                       int64_t cap_points);
 
+/* one-call forms of the geometry slot: pcc_octree_encode = root cube from the
+ * first / last key + pcc_octree_levels + pcc_octree_pack (utils.gpcc_encode,
+ * shared/utils.py:169-207); pcc_octree_decode = pcc_octree_peek (+ unpack when
+ * h_points is given) (utils.gpcc_decode, shared/utils.py:210-240, without the
+ * `* 8`). */
+int pcc_octree_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                      int key_shift, uint8_t* h_out, int64_t cap, int64_t* h_len);
+int pcc_octree_decode(const uint8_t* h_in, int64_t len, int32_t* h_points,
+                      int64_t cap_points, int64_t* h_n_points);
+
+/* ---- whole-GOP entry points ------------------------------ */
+
+/* replaces: CompressionPipeline.compress() (sender/encoder/codec_pipeline.py:
+ * 196-236, called from sender/encoder/encoder.py:139) and
+ * DecompressionPipeline.decompress() (receiver/decoder/codec_parallel.py:141-171,
+ * called from receiver/decoder/decoder.py:62) for one GOP, in native code: the
+ * op-level entry points above driven in the reference's stage order.  The
+ * containers are byte-identical to those of the Python mirror of the pipelines
+ * (codec_pipeline.py / codec_parallel.py of this package), which drives the same
+ * entry points one by one.
+ *
+ * A codec = model weights in HBM + one ctx (stream, scratch) + a device pool
+ * for the tensors of one call + pinned staging: one codec per in-flight call
+ * (the reference runs up to 3, sender/encoder/encoder.py:50).  Results (output
+ * containers, reconstructed cloud) are owned by the codec and stay valid until
+ * the next call on it.
+ *
+ * h_ckpt: "PCCW" blob = u32 count, then per tensor { u16 name_len, name, u8 dtype
+ * (0 float32, 1 int32), u8 ndim, u32 dims[], u64 nbytes, pad to 8, data, pad to
+ * 8 }, little-endian — the tensors of assets/demo_small.npz (DESIGN.md MODEL);
+ * native.pack_checkpoint() writes it. */
+typedef struct pcc_codec pcc_codec;
+typedef struct pcc_buf {
+  const uint8_t* data;
+  int64_t len;
+} pcc_buf;
+typedef struct pcc_cloud_info {
+  int64_t n_points;
+  int32_t n_frames;         /* frames the container announces                      */
+  int32_t n_offsets;        /* entries of h_offsets = frames with points, plus one */
+  const int64_t* h_offsets; /* row range of every frame in d_coords / d_colors     */
+  const int32_t* d_coords;  /* [n_points,4] rows (b,x,y,z), Morton order per frame */
+  const float* d_colors;    /* [n_points,3] as the colour head leaves them         */
+  double q_g, q_a;          /* quality setting read from the container             */
+} pcc_cloud_info;
+
+pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device, void* stream);
+void pcc_codec_destroy(pcc_codec* codec);
+pcc_ctx* pcc_codec_ctx(pcc_codec* codec); /* the codec's ctx (stream, profiler) */
+
+/* d_coords int32 [n,4] rows (b,x,y,z), b in [0,n_frames); d_feats float32 [n,4]
+ * = (1,r,g,b) (codec_pipeline.py:258); h_q [n_q,2] = (q_g,q_a) per quality
+ * (shared/config.yaml:12-15).  h_out receives n_q containers; h_k (nullable)
+ * int64 [3,n_frames] = k[scale][frame]; h_stage_s (nullable) double[7] seconds =
+ * analysis, hyper_analysis, factorized_model, hyper_synthesis,
+ * geometry_compression, gaussian_model, bitstream_writing.
+ * Errors: PCC_E_RANGE / PCC_E_DUP for bad coordinates, like the SparseTensor
+ * constructor of the Python mirror. */
+int pcc_encode_gop(pcc_codec* codec, const int32_t* d_coords,
+                   const float* d_feats, int64_t n, int n_frames,
+                   const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k,
+                   double* h_stage_s);
+/* h_stage_s (nullable) double[6] seconds = bitstream_reading,
+ * geometry_decompression, factorized_model, hyper_synthesis, guassian_model,
+ * synthesis_transform.  Truncated / inconsistent containers: PCC_E_STREAM. */
+int pcc_decode_gop(pcc_codec* codec, const uint8_t* h_in, int64_t len,
+                   pcc_cloud_info* h_info, double* h_stage_s);
+/* copy the cloud of the last pcc_decode_gop into caller-owned device buffers
+ * (int32 [n_points,4], float32 [n_points,3]; either may be NULL); returns when
+ * the copies are complete */
+int pcc_decode_fetch(pcc_codec* codec, int32_t* d_coords, float* d_colors);
+
 /* ---- capture pre-step ------------------------------- */
 
 /* replaces: the voxelisation the capturer does per camera frame with numpy +

@@ -1,0 +1,98 @@
+"""Whole-GOP C entry points (pcc_encode_gop / pcc_decode_gop) against the op-by-op Python
+mirror of the reference's stage methods and against the CPU oracle: containers byte for byte,
+reconstructions bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+SETTINGS = [[1.0, 0.0], [0.0, 1.0], [1, 1]]
+
+
+def _stack(frames):
+    pts = np.concatenate([np.concatenate([np.full((f["points"].shape[0], 1), i), f["points"].astype(np.int64)], 1)
+                          for i, f in enumerate(frames)], 0).astype(np.int32)
+    col = np.concatenate([f["colors"] for f in frames], 0).astype(np.float32)
+    feats = np.concatenate([np.ones((col.shape[0], 1), np.float32), col], 1)
+    return torch.from_numpy(pts).cuda(), torch.from_numpy(np.ascontiguousarray(feats)).cuda()
+
+
+@pytest.fixture(scope="module")
+def codec():
+    native = pkg("native")
+    model = pkg("model")
+    c = native.NativeCodec(model.load_checkpoint("demo_small"), 0)
+    yield c
+    c.close()
+
+
+def _gops(wl):
+    rng = np.random.default_rng(3)
+    g = {
+        "sphere2": [wl.sphere_shell(32, 11.2, seed=1, offset=(-40, 8, -90)), wl.sphere_shell(24, 9.1, seed=2)],
+        "sphere1": [wl.sphere_shell(40, 15.0, seed=5)],
+        "body3": [wl.body(20000, seed=s) for s in (1, 2, 3)],
+        "lidar": [wl.lidar_sweep(16, 600, seed=4)],
+    }
+    return g
+
+
+@pytest.mark.parametrize("name", ["sphere2", "sphere1", "body3", "lidar"])
+def test_native_gop_equals_python_ops_and_oracle(wl, oracle, codec, name):
+    frames = _gops(wl)[name]
+    enc = pkg("codec_pipeline").CompressionPipeline(SETTINGS, slots=1, engine="ops")
+    dec = pkg("codec_parallel").DecompressionPipeline(slots=1, engine="ops")
+    out, side = enc.compress(wl.gop([dict(f) for f in frames]))
+    coords, feats = _stack(frames)
+    cont, ks, times = codec.encode(coords, feats, len(frames), SETTINGS)
+    for q in range(len(SETTINGS)):
+        assert cont[q] == out[q + 1], f"container {q + 1} differs from the op-by-op path"
+    assert set(times) == set(side["enc_time_measurements"])
+    ref, _ = oracle.compress(frames, SETTINGS)
+    for q in range(len(SETTINGS)):
+        assert cont[q] == ref[q + 1], f"container {q + 1} differs from the oracle"
+    # decode: native vs op-by-op path vs oracle
+    for q in (1, 3):
+        rec, _ = dec.decompress(out[q])
+        c, col, offs, qq, dts = codec.decode(cont[q - 1])
+        assert qq == [float(v) for v in SETTINGS[q - 1]]
+        assert len(offs) - 1 == len(rec)
+        ch, colh = c.cpu().numpy(), col.cpu().numpy()
+        oref = oracle.decompress(ref[q])
+        for i, fr in enumerate(rec):
+            assert np.array_equal(ch[offs[i]:offs[i + 1], 1:], fr["points"])
+            assert np.all(ch[offs[i]:offs[i + 1], 0] == i)
+            item = np.clip(np.nan_to_num(colh[offs[i]:offs[i + 1]], nan=0.0) * 255.0, 0, 255) / 255
+            assert np.array_equal(item, fr["colors"])
+            assert np.array_equal(fr["points"], oref[i]["points"]) and np.array_equal(fr["colors"], oref[i]["colors"])
+
+
+def test_native_errors(codec):
+    native = pkg("native")
+    pts = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3]], dtype=torch.int32).cuda()
+    feats = torch.ones((2, 4), dtype=torch.float32).cuda()
+    with pytest.raises(native.PccError) as e:
+        codec.encode(pts, feats, 1, SETTINGS)
+    assert e.value.code == -4
+    far = torch.tensor([[0, 40000, 0, 0]], dtype=torch.int32).cuda()
+    with pytest.raises(native.PccError) as e:
+        codec.encode(far, torch.ones((1, 4)).cuda(), 1, SETTINGS)
+    assert e.value.code == -3
+    with pytest.raises(native.PccError) as e:
+        codec.decode(b"\x00" * 20)
+    assert e.value.code == -5
+
+
+def test_native_truncated_container(wl, codec):
+    frames = [wl.sphere_shell(24, 9.1, seed=2)]
+    coords, feats = _stack(frames)
+    cont, _, _ = codec.encode(coords, feats, 1, [[1, 1]])
+    native = pkg("native")
+    for cut in (37, len(cont[0]) // 2, len(cont[0]) - 3):
+        with pytest.raises(native.PccError):
+            codec.decode(cont[0][:cut])
+    c, col, offs, _, _ = codec.decode(cont[0])       # the codec is still usable afterwards
+    assert c.shape[0] == frames[0]["points"].shape[0]
