@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <chrono>
 #include <deque>
+#include <exception>
+#include <new>
 #include <map>
 #include <string>
 #include <thread>
@@ -124,6 +126,7 @@ struct CS {
   CS* down = nullptr;  // parents at stride*2 + the kernel-2 rule book [8, down->n]
   int32_t* nbr8 = nullptr;
   int32_t* parent_of = nullptr;
+  CS* up = nullptr;          // generative children at stride/2, once made
   CS* gen_parent = nullptr;  // set whose generative children these rows are (row 8p+o)
   CS* subset_of = nullptr;   // candidate set this set was pruned from, with the kept rows
   uint32_t* keep = nullptr;
@@ -214,6 +217,10 @@ int down_of(pcc_codec* cd, CS* s) {
 }
 
 int up_of(pcc_codec* cd, CS* s, CS** out) {
+  if (s->up) {
+    *out = s->up;
+    return PCC_OK;
+  }
   if (s->stride < 2) {
     pcc_set_error("codec: cannot up-sample a stride-1 coordinate set");
     return PCC_E_ARG;
@@ -222,6 +229,7 @@ int up_of(pcc_codec* cd, CS* s, CS** out) {
   if (s->n > 0) PCC_TRY(pcc_up_coords(cd->ctx, s->keys, s->n, 3 * (log2i(s->stride) - 1), ckeys));
   CS* c = new_set(cd, ckeys, 8 * s->n, s->stride / 2, s->n_batch);
   c->gen_parent = s;
+  s->up = c;
   *out = c;
   return PCC_OK;
 }
@@ -576,9 +584,8 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
 extern "C" pcc_ctx* pcc_codec_ctx(pcc_codec* cd) { return cd ? cd->ctx : nullptr; }
 
 // ---------------------------------------------------------------------------- encode
-extern "C" int pcc_encode_gop(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n,
-                              int n_frames, const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k,
-                              double* h_stage_s) {
+static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n, int n_frames,
+                           const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s) {
   PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_encode_gop: null codec");
   PCC_REQUIRE(n > 0 && d_coords && d_feats && n_frames >= 1 && n_frames <= 65535 && h_q && n_q >= 1 &&
                   n_q <= 64 && h_out,
@@ -872,8 +879,8 @@ extern "C" int pcc_encode_gop(pcc_codec* cd, const int32_t* d_coords, const floa
 }
 
 // ---------------------------------------------------------------------------- decode
-extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_cloud_info* h_info,
-                              double* h_stage_s) {
+static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_cloud_info* h_info,
+                           double* h_stage_s) {
   PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_decode_gop: null codec");
   PCC_REQUIRE(h_in && len >= 36 && h_info, PCC_E_STREAM, "pcc_decode_gop: container shorter than its header");
   pcc_ctx* ctx = cd->ctx;
@@ -911,6 +918,23 @@ extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, p
   }
   ts[0] = now_s() - t0;
 
+  // point counts the blobs announce, checked against the header BEFORE anything is sized from them:
+  // a rANS symbol costs at least ~2^-16 bit and an octree point at least a fraction of a bit, so a
+  // count far beyond what the payload can hold is a corrupt header, not a big frame
+  int64_t ny = 0;
+  std::vector<int64_t> fn((size_t)n_frames, 0);
+  for (int f = 0; f < n_frames; ++f) {
+    int depth;
+    int32_t org[3];
+    PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, &fn[f], &depth, org));
+    PCC_REQUIRE(fn[f] >= 0 && fn[f] <= ((int64_t)slots[f].len + 64) * 4096, PCC_E_STREAM,
+                "pcc_decode_gop: frame %d announces %lld points in a %d-byte blob", f, (long long)fn[f], slots[f].len);
+    ny += fn[f];
+  }
+  PCC_REQUIRE(ny == ny_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_y=%d, geometry gives %lld", ny_hdr,
+              (long long)ny);
+  PCC_REQUIRE(nz_hdr <= ny_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_z=%d > N_y=%d", nz_hdr, ny_hdr);
+
   // z string: nothing from the GPU is needed, decode it on a helper thread right away
   const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
                *eb_off = find(cd, "entropy_bottleneck.offset");
@@ -935,16 +959,6 @@ extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, p
 
   // ---- step 2: latent coordinates of every frame (codec_parallel.py:266-289)
   t0 = now_s();
-  int64_t ny = 0;
-  std::vector<int64_t> fn((size_t)n_frames, 0);
-  for (int f = 0; f < n_frames; ++f) {
-    int depth;
-    int32_t org[3];
-    PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, &fn[f], &depth, org));
-    ny += fn[f];
-  }
-  PCC_REQUIRE(ny == ny_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_y=%d, geometry gives %lld", ny_hdr,
-              (long long)ny);
   PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
   int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
   int n_batch = 0;
@@ -1052,6 +1066,13 @@ extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, p
       PCC_TRY(cd->pin_dec.ensure((size_t)tot * 4));
       PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p, idx8, (size_t)tot, hipMemcpyDeviceToHost, st));
       PCC_HIP(hipStreamSynchronize(st));
+      {  // coordinates and rule book of the first synthesis stage do not depend on the y values:
+         // the GPU builds them while the host decodes the y stream
+        CS* c0;
+        int32_t* nbr0;
+        PCC_TRY(up_of(cd, ycs, &c0));
+        PCC_TRY(nbr27_of(cd, c0, &nbr0));
+      }
       PCC_TRY(pcc_rans_decode8(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(),
                                gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p));
       PCC_HIP(hipMemcpyAsync(sym_d, cd->pin_dec.p, (size_t)tot * 4, hipMemcpyHostToDevice, st));
@@ -1138,6 +1159,34 @@ extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, p
   h_info->q_a = qa;
   if (h_stage_s) memcpy(h_stage_s, ts, 6 * sizeof(double));
   return PCC_OK;
+}
+
+// the library never throws across the ABI: allocation failures of the host containers become codes
+extern "C" int pcc_encode_gop(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n,
+                              int n_frames, const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k,
+                              double* h_stage_s) {
+  try {
+    return encode_gop_impl(cd, d_coords, d_feats, n, n_frames, h_q, n_q, h_out, h_k, h_stage_s);
+  } catch (const std::bad_alloc&) {
+    pcc_set_error("pcc_encode_gop: out of host memory");
+    return PCC_E_NOMEM;
+  } catch (const std::exception& e) {
+    pcc_set_error("pcc_encode_gop: %s", e.what());
+    return PCC_E_ARG;
+  }
+}
+
+extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_cloud_info* h_info,
+                              double* h_stage_s) {
+  try {
+    return decode_gop_impl(cd, h_in, len, h_info, h_stage_s);
+  } catch (const std::bad_alloc&) {
+    pcc_set_error("pcc_decode_gop: out of host memory");
+    return PCC_E_NOMEM;
+  } catch (const std::exception& e) {
+    pcc_set_error("pcc_decode_gop: %s", e.what());
+    return PCC_E_STREAM;
+  }
 }
 
 extern "C" int pcc_decode_fetch(pcc_codec* cd, int32_t* d_coords, float* d_colors) {

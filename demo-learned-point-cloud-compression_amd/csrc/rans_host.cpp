@@ -39,27 +39,6 @@ constexpr uint32_t kBypassBits = 4;
 constexpr uint32_t kMaxBypass = (1u << kBypassBits) - 1;  // 15
 constexpr uint64_t kRansL = 1ull << 31;
 
-// Exact x / d for every 64-bit x and 1 <= d <= 65536 without a divide instruction
-// (Granlund & Montgomery, "Division by invariant integers using multiplication", fig. 4.1,
-// N = 64): l = ceil(log2 d), m = floor(2^64 (2^l - d) / d) + 1,
-// q = (t + ((x - t) >> min(l,1))) >> max(l-1,0) with t = mulhi(m, x).
-struct Rcp {
-  uint64_t m;
-  uint8_t sh1, sh2;
-};
-static Rcp g_rcp[65537];
-static const bool g_rcp_init = [] {
-  for (uint32_t d = 1; d <= 65536; ++d) {
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;
-    const unsigned __int128 num = (unsigned __int128)((1ull << l) - d) << 64;
-    g_rcp[d].m = (uint64_t)(num / d) + 1;
-    g_rcp[d].sh1 = (uint8_t)(l < 1 ? l : 1);
-    g_rcp[d].sh2 = (uint8_t)(l > 0 ? l - 1 : 0);
-  }
-  return true;
-}();
-
 struct Enc {
   uint64_t x;
   uint32_t* ptr;    // next word is written at --ptr
@@ -70,16 +49,7 @@ struct Enc {
     if (ptr == floor) { overflow = true; return; }
     *--ptr = w;
   }
-  inline void put(uint32_t start, uint32_t freq) {
-    const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
-    if (x >= x_max) { emit((uint32_t)x); x >>= 32; }
-    const Rcp& r = g_rcp[freq];
-    const uint64_t t = (uint64_t)(((unsigned __int128)r.m * x) >> 64);
-    const uint64_t q = (t + ((x - t) >> r.sh1)) >> r.sh2;   // == x / freq
-    x = (q << kPrecision) + (x - q * freq) + start;
-  }
-  // same step from a precomputed per-symbol entry (one 32-byte load instead of cdf[v], cdf[v+1] and
-  // the 1 MB reciprocal table)
+  // one coding step from a precomputed per-symbol entry (one 32-byte load)
   inline void put(const struct EncSym& e);
   inline void put_bits(uint32_t val) {
     const uint32_t freq = 1u << (16 - kBypassBits);
@@ -89,17 +59,23 @@ struct Enc {
   }
 };
 
+// Per-symbol encoder entry.  The division x / freq is a multiply by ceil(2^(shift+63) / freq) with
+// shift = ceil(log2 freq) (Alverson, "Integer division using reciprocals"; the form ryg_rans's
+// Rans64EncSymbol uses): exact for every state the coder can hold (x < 2^63; checked against x / freq
+// for all 65535 frequencies on 1.3e8 states incl. both ends of the renormalisation interval), and the
+// update (x / freq) << 16 + x % freq + start becomes x + bias + q * (2^16 - freq).
 struct EncSym {
-  uint64_t m;       // reciprocal multiplier of freq
+  uint64_t rcp;     // reciprocal of freq
   uint64_t x_max;   // renormalisation threshold ((L >> 16) << 32) * freq
-  uint32_t start, freq;
-  uint8_t sh1, sh2;
+  uint32_t bias;    // start (freq == 1: start + 2^16 - 1, with rcp = ~0, shift 0)
+  uint32_t cmpl;    // 2^16 - freq
+  uint32_t freq;    // 0 marks an unusable bin
+  uint32_t rs;      // shift - 1
 };
 inline void Enc::put(const EncSym& e) {
   if (x >= e.x_max) { emit((uint32_t)x); x >>= 32; }
-  const uint64_t t = (uint64_t)(((unsigned __int128)e.m * x) >> 64);
-  const uint64_t q = (t + ((x - t) >> e.sh1)) >> e.sh2;   // == x / freq
-  x = (q << kPrecision) + (x - q * e.freq) + e.start;
+  const uint64_t q = (uint64_t)(((unsigned __int128)e.rcp * x) >> 64) >> e.rs;   // == x / freq
+  x = x + e.bias + q * e.cmpl;
 }
 
 inline int n_nibbles(uint32_t raw) {
@@ -131,10 +107,19 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
     for (int v = 0; v < sizes[c] - 1; ++v) {
       EncSym& e = ent[(size_t)base[c] + v];
       const int64_t f = (int64_t)cdf[v + 1] - cdf[v];
-      e.start = (uint32_t)cdf[v];
       e.freq = (f >= 1 && f <= 65536) ? (uint32_t)f : 0u;   // 0 marks an unusable bin (checked at use)
-      const Rcp& r = g_rcp[e.freq ? e.freq : 1];
-      e.m = r.m; e.sh1 = r.sh1; e.sh2 = r.sh2;
+      e.bias = (uint32_t)cdf[v];
+      e.cmpl = (1u << kPrecision) - e.freq;
+      if (e.freq < 2) {
+        e.rcp = ~0ull;
+        e.rs = 0;
+        e.bias += (1u << kPrecision) - 1;
+      } else {
+        uint32_t shift = 0;
+        while (e.freq > (1u << shift)) ++shift;
+        e.rcp = (uint64_t)((((unsigned __int128)1 << (shift + 63)) + e.freq - 1) / e.freq);
+        e.rs = shift - 1;
+      }
       e.x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)e.freq;
     }
   }
@@ -226,7 +211,7 @@ int encode_multi(const SymT* h_sym, const IdxT* h_idx, int64_t n, int n_streams,
 // a short forward scan finishes it (same result as CompressAI's linear std::find_if over the CDF).
 struct DecTab {
   const uint32_t* sym;   // [size - 1]
-  const uint16_t* lut;   // [1024]
+  const uint64_t* lut;   // [1024]: start | freq << 16 | symbol << 32 | ambiguous << 63
   int32_t max_value, offset;
 };
 constexpr int kLutBits = 10;
@@ -256,7 +241,7 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
   std::vector<uint8_t> used((size_t)n_cdf, 0);
   for (int64_t i = 0; i < n; ++i) used[(size_t)(int32_t)h_idx[i]] = 1;
   std::vector<DecTab> tabs((size_t)n_cdf);
-  std::vector<uint16_t> luts((size_t)n_cdf << kLutBits);
+  std::vector<uint64_t> luts((size_t)n_cdf << kLutBits);
   size_t total = 0;
   for (int c = 0; c < n_cdf; ++c) {
     if (!used[c]) continue;
@@ -274,11 +259,16 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
     const int size = h_sizes[c];
     uint32_t* sy = syms.data() + total;
     for (int v = 0; v < size - 1; ++v) sy[v] = ((uint32_t)(cdf[v + 1] - cdf[v]) << 16) | ((uint32_t)cdf[v] & 0xFFFFu);
-    uint16_t* lut = luts.data() + ((size_t)c << kLutBits);
-    int s = 0;  // lut[b] = largest s <= max_value with cdf[s] <= b << (16 - kLutBits)
+    // lut[b]: s = largest symbol <= max_value with cdf[s] <= first slot of bucket b, together with its
+    // (start, freq) so that a bucket lying inside ONE symbol's interval resolves with this single load;
+    // a bucket that a CDF boundary cuts is flagged and finishes with the forward scan
+    uint64_t* lut = luts.data() + ((size_t)c << kLutBits);
+    int s = 0;
     for (int b = 0; b < (1 << kLutBits); ++b) {
-      while (s + 1 < size - 1 && cdf[s + 1] <= (b << (16 - kLutBits))) ++s;
-      lut[b] = (uint16_t)s;
+      const int lo = b << (16 - kLutBits), hi = lo + (1 << (16 - kLutBits));
+      while (s + 1 < size - 1 && cdf[s + 1] <= lo) ++s;
+      const bool cut = s + 1 < size - 1 && cdf[s + 1] < hi;
+      lut[b] = (uint64_t)sy[s] | ((uint64_t)s << 32) | ((uint64_t)cut << 63);
     }
     tabs[c].sym = sy;
     tabs[c].lut = lut;
@@ -301,10 +291,14 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
   for (int64_t i = 0; i < n; ++i) {
     const DecTab& t = tabs[(size_t)(int32_t)h_idx[i]];
     const uint32_t cum = (uint32_t)(x & 0xFFFFu);
-    int32_t s = t.lut[cum >> (16 - kLutBits)];
-    // forward scan: entry s+1 starts at (sym[s+1] & 0xFFFF); == find_if(v > cum) - 1
-    while (s < t.max_value && (t.sym[s + 1] & 0xFFFFu) <= cum) ++s;
-    const uint32_t e = t.sym[s];
+    const uint64_t l = t.lut[cum >> (16 - kLutBits)];
+    int32_t s = (int32_t)((l >> 32) & 0xFFFFu);
+    uint32_t e = (uint32_t)l;
+    if (__builtin_expect((int64_t)l < 0, 0)) {
+      // forward scan: entry s+1 starts at (sym[s+1] & 0xFFFF); == find_if(v > cum) - 1
+      while (s < t.max_value && (t.sym[s + 1] & 0xFFFFu) <= cum) ++s;
+      e = t.sym[s];
+    }
     x = (uint64_t)(e >> 16) * (x >> kPrecision) + cum - (e & 0xFFFFu);
     if (x < kRansL) x = (x << 32) | word(bad);
     int32_t value = s;
