@@ -266,3 +266,36 @@ def test_scale_nn_host_mirror_matches_oracle(oracle):
     q = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [0.3, 0.7]], dtype=np.float32)
     assert np.array_equal(s(q), oracle.scale_nn(q))
     assert np.all(s(q) >= 0.5)
+
+
+def test_checkpoint_blob_layout_and_no_cpu_fallback_of_the_native_engine():
+    """native.pack_checkpoint writes the "PCCW" blob pcc_codec_create parses (include/pcc.h); without a HIP
+    device the native engine refuses to run instead of falling back to anything"""
+    import struct
+    native = pkg("native")
+    t = {"a.weight": np.arange(6, dtype=np.float64).reshape(2, 3), "tab": np.array([5, -7], dtype=np.int64),
+         "s": np.float32(1.5)}
+    blob = native.pack_checkpoint(t)
+    assert blob[:4] == b"PCCW" and struct.unpack_from("<I", blob, 4)[0] == 3
+    pos, seen = 8, {}
+    for _ in range(3):
+        (nl,) = struct.unpack_from("<H", blob, pos)
+        name = blob[pos + 2:pos + 2 + nl].decode()
+        pos += 2 + nl
+        dt, nd = struct.unpack_from("<BB", blob, pos)
+        dims = struct.unpack_from(f"<{nd}I", blob, pos + 2)
+        (nb,) = struct.unpack_from("<Q", blob, pos + 2 + 4 * nd)
+        pos = (pos + 2 + 4 * nd + 8 + 7) & ~7
+        seen[name] = np.frombuffer(blob, dtype="<f4" if dt == 0 else "<i4", count=nb // 4, offset=pos).reshape(dims)
+        pos = (pos + nb + 7) & ~7
+    assert pos == len(blob)
+    assert np.array_equal(seen["a.weight"], t["a.weight"].astype(np.float32)) and seen["a.weight"].dtype == np.float32
+    assert seen["tab"].tolist() == [5, -7] and seen["s"].reshape(-1).tolist() == [1.5]   # 0-d tensors travel as [1]
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            native.NativeCodec(t, 0)
+        lib = pkg("_abi").lib()
+        assert not lib.pcc_codec_create(blob, len(blob), 0, None)          # no device: NULL + error text, no crash
+        assert lib.pcc_last_error()
+        assert not lib.pcc_codec_create(b"nope" + blob[4:], len(blob), 0, None)
