@@ -96,3 +96,52 @@ def test_native_truncated_container(wl, codec):
             codec.decode(cont[0][:cut])
     c, col, offs, _, _ = codec.decode(cont[0])       # the codec is still usable afterwards
     assert c.shape[0] == frames[0]["points"].shape[0]
+
+
+def test_native_edge_gops(wl, oracle, codec):
+    """ragged GOP through pcc_encode_gop / pcc_decode_gop: a one-voxel frame, frames at the int16 corners of the
+    coordinate range, ten frames, and a middle frame that prunes to nothing at the coarse levels"""
+    rng = np.random.default_rng(9)
+
+    def cloud(n, lo, hi):
+        p = np.unique(rng.integers(lo, hi, (n, 3)), axis=0).astype(np.int16)
+        return {"points": p, "colors": rng.random((p.shape[0], 3))}
+
+    gops = {
+        "one_voxel_and_sphere": [{"points": np.array([[5, -3, 7]], np.int16), "colors": np.array([[0.2, 0.4, 0.6]])},
+                                 wl.sphere_shell(24, 9.1, seed=2)],
+        "corners": [cloud(3000, -32768, -32700), cloud(3000, 32700, 32767)],
+        "ten_frames": [wl.sphere_shell(16 + f, 5.0 + f, seed=f, offset=(7 * f, -3 * f, f)) for f in range(10)],
+        "dust": [cloud(400, -3000, 3000), wl.sphere_shell(20, 7.7, seed=3), cloud(2, -10, 10)],
+    }
+    settings = [[1, 1], [0.25, 0.75]]
+    for name, frames in gops.items():
+        coords, feats = _stack(frames)
+        cont, ks, _ = codec.encode(coords, feats, len(frames), settings)
+        ref, _ = oracle.compress(frames, settings)
+        assert cont[0] == ref[1] and cont[1] == ref[2], name
+        assert ks[2] == [f["points"].shape[0] for f in frames], name
+        c, col, offs, _, _ = codec.decode(cont[1])
+        oref = oracle.decompress(ref[2])
+        ch, colh = c.cpu().numpy(), col.cpu().numpy()
+        assert len(offs) - 1 == len(oref), name
+        for i, fr in enumerate(oref):
+            assert np.array_equal(ch[offs[i]:offs[i + 1], 1:], fr["points"]), name
+            item = np.clip(np.nan_to_num(colh[offs[i]:offs[i + 1]], nan=0.0) * 255.0, 0, 255) / 255
+            assert np.array_equal(item, fr["colors"]), name
+
+
+def test_native_codec_reuse_across_sizes(wl, codec):
+    """the per-codec device pool and pinned buffers are reused: big GOP, small GOP, big GOP again, same bytes"""
+    big = [wl.body(120000, seed=1)]
+    small = [wl.sphere_shell(16, 5.5, seed=1)]
+    cb, fb = _stack(big)
+    cs_, fs = _stack(small)
+    a1, _, _ = codec.encode(cb, fb, 1, SETTINGS)
+    s1, _, _ = codec.encode(cs_, fs, 1, SETTINGS)
+    a2, _, _ = codec.encode(cb, fb, 1, SETTINGS)
+    s2, _, _ = codec.encode(cs_, fs, 1, SETTINGS)
+    assert a1 == a2 and s1 == s2
+    n1 = codec.decode(a1[2])[0].shape[0]
+    n2 = codec.decode(s1[2])[0].shape[0]
+    assert n1 == big[0]["points"].shape[0] and n2 == small[0]["points"].shape[0]
