@@ -1116,8 +1116,9 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
       new_offs.push_back(new_offs.back() + kj[f]);
     }
     CODEC_ALLOC(keep, uint32_t, std::max<int64_t>(nu, 1));
-    int64_t n_keep = 0;
-    if (nu > 0) PCC_TRY(pcc_topk_prune(ctx, logits, nu, nb, offs->data(), kj.data(), keep, &n_keep));
+    // exact top-k keeps sum_f kj[f] rows: no count to read back, the stage stays asynchronous
+    const int64_t n_keep = new_offs.back();
+    if (nu > 0) PCC_TRY(pcc_topk_prune(ctx, logits, nu, nb, offs->data(), kj.data(), keep, nullptr));
     CODEC_ALLOC(pkeys, uint64_t, std::max<int64_t>(n_keep, 1));
     CODEC_ALLOC(pf, float, std::max<int64_t>(n_keep, 1) * cout);
     if (n_keep > 0) {

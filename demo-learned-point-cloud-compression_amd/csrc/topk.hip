@@ -116,12 +116,25 @@ __global__ void k_topk_emit(const uint32_t* __restrict__ keep, const uint32_t* _
   if (i < n && keep[i]) rows[keep_ex[i]] = (uint32_t)i;
 }
 
+// per-frame parameters of a small GOP travel as kernel arguments: no pinned staging, hence no
+// stream synchronisation on their account
+#define TOPK_ARG_FRAMES 8
+struct TopkArgs {
+  int64_t offs[TOPK_ARG_FRAMES + 1];
+  TopkState st[TOPK_ARG_FRAMES];
+};
+__global__ void k_topk_params(TopkArgs a, int n_batch, int64_t* __restrict__ offs, TopkState* __restrict__ state) {
+  const int t = threadIdx.x;
+  if (t <= n_batch) offs[t] = a.offs[t];
+  if (t < n_batch) state[t] = a.st[t];
+}
+
 extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, int n_batch,
                               const int64_t* h_offsets, const int64_t* h_k, uint32_t* d_keep_rows,
                               int64_t* h_n_keep) {
-  PCC_REQUIRE(ctx && h_n_keep && h_offsets && h_k, PCC_E_ARG, "pcc_topk_prune: null arg");
+  PCC_REQUIRE(ctx && h_offsets && h_k, PCC_E_ARG, "pcc_topk_prune: null arg");
   PCC_REQUIRE(n_batch >= 1 && n_batch <= 120, PCC_E_ARG, "pcc_topk_prune: n_batch=%d", n_batch);
-  *h_n_keep = 0;
+  if (h_n_keep) *h_n_keep = 0;
   if (n <= 0) return PCC_OK;
   PCC_REQUIRE(d_logits && d_keep_rows, PCC_E_ARG, "pcc_topk_prune: null buffers");
   PCC_REQUIRE(n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_topk_prune: n too large");
@@ -141,11 +154,14 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
   const size_t mark = ctx->arena_off;
   PccProfScope prof(ctx, "topk_prune", n, n_batch, 0, 0);
 
-  // stage per-frame parameters through the pinned buffer
+  // per-frame parameters: kernel arguments for small GOPs, else staged through the pinned buffer
+  const bool by_arg = n_batch <= TOPK_ARG_FRAMES;
+  TopkArgs args;
   char* hp = (char*)ctx->pinned;
   int64_t max_cnt = 0;
-  memcpy(hp, h_offsets, (size_t)(n_batch + 1) * 8);
-  TopkState* hs = (TopkState*)(hp + (size_t)(n_batch + 1) * 8);
+  if (by_arg) memcpy(args.offs, h_offsets, (size_t)(n_batch + 1) * 8);
+  else memcpy(hp, h_offsets, (size_t)(n_batch + 1) * 8);
+  TopkState* hs = by_arg ? args.st : (TopkState*)(hp + (size_t)(n_batch + 1) * 8);
   for (int f = 0; f < n_batch; ++f) {
     const int64_t cnt = h_offsets[f + 1] - h_offsets[f];
     PCC_REQUIRE(cnt >= 0 && h_k[f] >= 0, PCC_E_ARG, "pcc_topk_prune: negative count/k in frame %d", f);
@@ -156,8 +172,13 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
     else if (h_k[f] >= cnt) { hs[f].mode = 1; hs[f].k_rem = 0; }
     else { hs[f].mode = 2; hs[f].k_rem = (uint32_t)h_k[f]; }
   }
-  PCC_HIP(hipMemcpyAsync(offs, hp, (size_t)(n_batch + 1) * 8, hipMemcpyHostToDevice, st));
-  PCC_HIP(hipMemcpyAsync(state, hs, sizeof(TopkState) * n_batch, hipMemcpyHostToDevice, st));
+  if (by_arg) {
+    hipLaunchKernelGGL(k_topk_params, dim3(1), dim3(64), 0, st, args, n_batch, offs, state);
+    PCC_CHECK_LAUNCH();
+  } else {
+    PCC_HIP(hipMemcpyAsync(offs, hp, (size_t)(n_batch + 1) * 8, hipMemcpyHostToDevice, st));
+    PCC_HIP(hipMemcpyAsync(state, hs, sizeof(TopkState) * n_batch, hipMemcpyHostToDevice, st));
+  }
   PCC_HIP(hipMemsetAsync(hist, 0, (size_t)256 * 4 * n_batch, st));
   // the pinned buffer is reused below only after the final synchronise
 
@@ -186,8 +207,12 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
   hipLaunchKernelGGL(k_topk_emit, dim3(nblk(n, 256)), dim3(256), 0, st, (const uint32_t*)fl,
                      (const uint32_t*)ex, n, d_keep_rows);
   PCC_CHECK_LAUNCH();
+  // the number of kept rows is sum_f min(k_f, cnt_f) by construction (exact top-k, ties broken by row):
+  // a caller that computes it itself passes h_n_keep = NULL and, for small GOPs, gets no synchronisation
+  if (!h_n_keep && by_arg) return PCC_OK;
   uint32_t* h = (uint32_t*)ctx->pinned;
   PCC_HIP(hipStreamSynchronize(st));  // staged parameters consumed; pinned buffer free again
+  if (!h_n_keep) return PCC_OK;
   PCC_HIP(hipMemcpyAsync(h, total, 4, hipMemcpyDeviceToHost, st));
   PCC_HIP(hipStreamSynchronize(st));
   *h_n_keep = (int64_t)h[0];
