@@ -145,3 +145,34 @@ def test_native_codec_reuse_across_sizes(wl, codec):
     n1 = codec.decode(a1[2])[0].shape[0]
     n2 = codec.decode(s1[2])[0].shape[0]
     assert n1 == big[0]["points"].shape[0] and n2 == small[0]["points"].shape[0]
+
+
+def test_octree_one_call_entry_points(rt, oracle):
+    """pcc_octree_encode / pcc_octree_decode (one call each) == the levels + pack / peek + unpack sequence that
+    utils.gpcc_encode / gpcc_decode drive, and == the oracle's blob"""
+    import ctypes as C
+    from conftest import surface_cloud
+    utils, rtm = pkg("utils"), pkg("runtime")
+    rng = np.random.default_rng(21)
+    coords = surface_cloud(rng, 5000, batches=1, stride=8)
+    keys_h = np.sort(oracle.morton_keys(coords))
+    keys = rt.to_device(keys_h.view(np.int64))
+    blob_ref = utils.gpcc_encode(keys, keys_h, 0, len(keys_h), 9)
+    cap = 64 + 16 * len(keys_h)
+    out = np.empty(cap, np.uint8)
+    n_out = C.c_int64(0)
+    rtm.check(rt.lib.pcc_octree_encode(rt.ctx, rtm._ptr(keys), len(keys_h), 9, out.ctypes.data, cap, C.byref(n_out)),
+              "pcc_octree_encode")
+    blob = out[:n_out.value].tobytes()
+    assert blob == blob_ref
+    n_pts = C.c_int64(0)
+    rtm.check(rt.lib.pcc_octree_decode(blob, len(blob), None, 0, C.byref(n_pts)), "pcc_octree_decode")
+    assert n_pts.value == len(keys_h)
+    pts = np.empty((n_pts.value, 3), np.int32)
+    rtm.check(rt.lib.pcc_octree_decode(blob, len(blob), pts.ctypes.data, n_pts.value, C.byref(n_pts)), "pcc_octree_decode")
+    assert np.array_equal(pts * 8, utils.gpcc_decode(blob, 8))
+    small = np.empty((1, 3), np.int32)
+    assert rt.lib.pcc_octree_decode(blob, len(blob), small.ctypes.data, 1, C.byref(n_pts)) == -6
+    # empty frame
+    rtm.check(rt.lib.pcc_octree_encode(rt.ctx, None, 0, 9, out.ctypes.data, cap, C.byref(n_out)), "pcc_octree_encode")
+    assert out[:n_out.value].tobytes() == utils.gpcc_encode(keys[:0], keys_h[:0], 0, 0, 9)
