@@ -798,27 +798,63 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_TRY(cd->pin_ysym.ensure((size_t)std::max<int64_t>(tot, 1) * 4));
     PCC_TRY(cd->pin_yidx.ensure((size_t)std::max<int64_t>(tot, 1) * 4));
     PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
-    if (ny > 0) {
+    if (ny > 0)
       PCC_TRY(pcc_gaussian_quant16(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
                                    ntab, sym16, idx8, flag));
-      PCC_HIP(hipMemcpyAsync(cd->pin_ysym.p, sym16, (size_t)tot * 2, hipMemcpyDeviceToHost, st));
-      PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p, idx8, (size_t)tot, hipMemcpyDeviceToHost, st));
-    }
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
-    PCC_HIP(hipStreamSynchronize(st));
+    // one copy + one event per quality: the stream of quality q is coded (on its own thread) as soon as its
+    // symbols have crossed PCIe, while the copies of the later qualities are still in flight
+    std::vector<hipEvent_t> evq((size_t)n_q, nullptr);
+    for (int q = 0; q < n_q; ++q) {
+      if (ny > 0) {
+        PCC_HIP(hipMemcpyAsync(cd->pin_ysym.p + (size_t)q * per * 2, sym16 + (size_t)q * per, (size_t)per * 2,
+                               hipMemcpyDeviceToHost, st));
+        PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p + (size_t)q * per, idx8 + (size_t)q * per, (size_t)per,
+                               hipMemcpyDeviceToHost, st));
+      }
+      PCC_HIP(hipEventCreateWithFlags(&evq[q], hipEventDisableTiming));
+      PCC_HIP(hipEventRecord(evq[q], st));
+    }
     std::vector<int64_t> lens((size_t)n_q, 0);
     std::vector<uint8_t> stage;
     int rc = PCC_OK;
     int64_t cap = 2 * per + 4096;
-    if (*(int32_t*)cd->pin_flag.p == 0) {
-      for (int attempt = 0; attempt < 2; ++attempt) {
-        stage.resize((size_t)cap * n_q);
-        rc = pcc_rans_encode_multi16((const int16_t*)cd->pin_ysym.p, cd->pin_yidx.p, per, n_q, gc_cdf->i32(),
-                                     (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0],
-                                     stage.data(), cap, lens.data());
-        if (rc != PCC_E_NOMEM) break;
-        cap = 48 * per + 4096;
+    std::vector<int> rcq((size_t)n_q, PCC_OK);
+    std::vector<std::string> errq((size_t)n_q);
+    auto code_quality = [&](int q) {
+      (void)hipSetDevice(cd->device);
+      if (hipEventSynchronize(evq[q]) != hipSuccess) {
+        rcq[q] = PCC_E_HIP;
+        errq[q] = "hipEventSynchronize failed";
+        return;
       }
+      if (*(volatile int32_t*)cd->pin_flag.p != 0) return;  // int16 overflow: the generic path below codes everything
+      int64_t capq = cap, got = 0;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        y_strings[q].resize((size_t)capq);
+        rcq[q] = pcc_rans_encode_multi16((const int16_t*)cd->pin_ysym.p + (size_t)q * per, cd->pin_yidx.p + (size_t)q * per,
+                                         per, 1, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(),
+                                         (int)gc_cdf->dims[0], y_strings[q].data(), capq, &got);
+        if (rcq[q] != PCC_E_NOMEM) break;
+        capq = 48 * per + 4096;
+      }
+      if (rcq[q] == PCC_OK) y_strings[q].resize((size_t)got);
+      else errq[q] = pcc_last_error();
+    };
+    {
+      std::vector<std::thread> th;
+      for (int q = 1; q < n_q; ++q) th.emplace_back(code_quality, q);
+      code_quality(0);
+      for (auto& t : th) t.join();
+    }
+    for (int q = 0; q < n_q; ++q) (void)hipEventDestroy(evq[q]);
+    for (int q = 0; q < n_q; ++q)
+      if (rcq[q] != PCC_OK) {
+        pcc_set_error("pcc_encode_gop (y stream %d): %s", q, errq[q].c_str());
+        return rcq[q];
+      }
+    if (*(int32_t*)cd->pin_flag.p == 0) {
+      // coded above
     } else {  // a symbol outside int16: the generic int32 form
       CODEC_ALLOC(sym32, int32_t, std::max<int64_t>(tot, 1));
       CODEC_ALLOC(idx32, int32_t, std::max<int64_t>(tot, 1));
@@ -835,10 +871,10 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         if (rc != PCC_E_NOMEM) break;
         cap = 48 * per + 4096;
       }
+      PCC_TRY(rc);
+      for (int q = 0; q < n_q; ++q)
+        y_strings[q].assign(stage.begin() + (size_t)q * cap, stage.begin() + (size_t)q * cap + (size_t)lens[q]);
     }
-    PCC_TRY(rc);
-    for (int q = 0; q < n_q; ++q)
-      y_strings[q].assign(stage.begin() + (size_t)q * cap, stage.begin() + (size_t)q * cap + (size_t)lens[q]);
   }
   ts[5] = now_s() - t0;
 
