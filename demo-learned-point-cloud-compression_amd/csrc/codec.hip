@@ -92,6 +92,18 @@ struct DevPool {
   }
 };
 
+// hipEvent that cannot leak on an early return
+struct Event {
+  hipEvent_t e = nullptr;
+  int create() { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? PCC_OK : PCC_E_HIP; }
+  ~Event() {
+    if (e) (void)hipEventDestroy(e);
+  }
+  Event() = default;
+  Event(const Event&) = delete;
+  Event& operator=(const Event&) = delete;
+};
+
 struct Pinned {
   uint8_t* p = nullptr;
   size_t cap = 0;
@@ -722,8 +734,9 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_TRY(rows_to_tensor(cd, zv, zhat_rows, cz, &zf));
     z_hat = {z.cs, zf, cz};
   }
-  hipEvent_t ev_host;
-  PCC_HIP(hipEventCreateWithFlags(&ev_host, hipEventDisableTiming));
+  Event ev_host_own;
+  PCC_REQUIRE(ev_host_own.create() == PCC_OK, PCC_E_HIP, "pcc_encode_gop: hipEventCreate failed");
+  const hipEvent_t ev_host = ev_host_own.e;
   PCC_HIP(hipEventRecord(ev_host, st));
   // helper thread: geometry blobs + z string, neither feeds the GPU path
   std::vector<std::vector<uint8_t>> blobs((size_t)n_frames);
@@ -804,6 +817,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
     // one copy + one event per quality: the stream of quality q is coded (on its own thread) as soon as its
     // symbols have crossed PCIe, while the copies of the later qualities are still in flight
+    std::vector<Event> evq_own((size_t)n_q);
     std::vector<hipEvent_t> evq((size_t)n_q, nullptr);
     for (int q = 0; q < n_q; ++q) {
       if (ny > 0) {
@@ -812,7 +826,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p + (size_t)q * per, idx8 + (size_t)q * per, (size_t)per,
                                hipMemcpyDeviceToHost, st));
       }
-      PCC_HIP(hipEventCreateWithFlags(&evq[q], hipEventDisableTiming));
+      PCC_REQUIRE(evq_own[q].create() == PCC_OK, PCC_E_HIP, "pcc_encode_gop: hipEventCreate failed");
+      evq[q] = evq_own[q].e;
       PCC_HIP(hipEventRecord(evq[q], st));
     }
     std::vector<int64_t> lens((size_t)n_q, 0);
@@ -842,12 +857,17 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       else errq[q] = pcc_last_error();
     };
     {
-      std::vector<std::thread> th;
-      for (int q = 1; q < n_q; ++q) th.emplace_back(code_quality, q);
+      struct JoinAll {  // joins whatever was started, also when starting a later thread throws
+        std::vector<std::thread> th;
+        ~JoinAll() {
+          for (auto& t : th)
+            if (t.joinable()) t.join();
+        }
+      } pool;
+      pool.th.reserve((size_t)n_q);
+      for (int q = 1; q < n_q; ++q) pool.th.emplace_back(code_quality, q);
       code_quality(0);
-      for (auto& t : th) t.join();
     }
-    for (int q = 0; q < n_q; ++q) (void)hipEventDestroy(evq[q]);
     for (int q = 0; q < n_q; ++q)
       if (rcq[q] != PCC_OK) {
         pcc_set_error("pcc_encode_gop (y stream %d): %s", q, errq[q].c_str());
@@ -879,7 +899,6 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   ts[5] = now_s() - t0;
 
   helper.join();
-  (void)hipEventDestroy(ev_host);
   if (helper_rc != PCC_OK) {
     pcc_set_error("pcc_encode_gop (host coders): %s", helper_err.c_str());
     return helper_rc;
