@@ -181,8 +181,15 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
   if (tid == 0) { s_or = 0ull; s_and = ~0ull; }
   __syncthreads();
   {
+    // one workgroup has nobody to hide a load's latency behind: keep 4 independent loads in flight per lane
     uint64_t o = 0, a = ~0ull;
-    for (int e = tid; e < n; e += SS_THREADS) { const uint64_t k = keys[e]; o |= k; a &= k; }
+    for (int e = tid; e < n; e += 4 * SS_THREADS) {
+      uint64_t k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k[u] = keys[min(e + u * SS_THREADS, n - 1)];  // clamped: duplicates are harmless
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { o |= k[u]; a &= k[u]; }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       o |= __shfl_xor((unsigned long long)o, d, 64);
@@ -197,7 +204,17 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
   // identity permutation, no pass at all
   {
     bool ok = true;
-    for (int e = tid + 1; e < n; e += SS_THREADS) ok &= (keys[e - 1] ^ flip) <= (keys[e] ^ flip);
+    for (int e = tid + 1; e < n; e += 4 * SS_THREADS) {
+      uint64_t lo[4], hi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = min(e + u * SS_THREADS, n - 1);
+        lo[u] = keys[q - 1];
+        hi[u] = keys[q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ok &= (lo[u] ^ flip) <= (hi[u] ^ flip);
+    }
     const bool all_ok = __syncthreads_and(ok);
     if (all_ok) {
       for (int e = tid; e < n; e += SS_THREADS) perm[e] = (uint32_t)e;
@@ -215,7 +232,14 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
     // (a) per-wave digit counts
     for (int d = lane; d < 256; d += 64) cnt[wave][d] = 0;
     __builtin_amdgcn_wave_barrier();
-    for (int e = c0 + lane; e < c1; e += 64) atomicAdd(&cnt[wave][(uint32_t)(((kin[e] ^ flip) >> shift) & 255u)], 1u);
+    for (int e = c0 + lane; e < c1; e += 256) {
+      uint64_t k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k[u] = kin[min(e + u * 64, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e + u * 64 < c1) atomicAdd(&cnt[wave][(uint32_t)(((k[u] ^ flip) >> shift) & 255u)], 1u);
+    }
     __syncthreads();
     // (b) counts -> exclusive offsets: digit-major, wave-minor
     uint32_t tot = 0;
@@ -238,12 +262,23 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
     __syncthreads();
     // (c) stable scatter of this wave's chunk
     volatile uint32_t* base = cnt[wave];
-    for (int e0 = c0; e0 < c1; e0 += 64) {
+    for (int eb = c0; eb < c1; eb += 256) {
+      uint64_t pk[4];
+      uint32_t pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = min(eb + u * 64 + lane, n - 1);
+        pk[u] = kin[q];
+        pv[u] = vin ? vin[q] : (uint32_t)q;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+      const int e0 = eb + u * 64;
+      if (e0 >= c1) break;  // wave-uniform
       const int e = e0 + lane;
       const bool valid = e < c1;
-      uint64_t key = 0;
-      uint32_t val = 0;
-      if (valid) { key = kin[e]; val = vin ? vin[e] : (uint32_t)e; }
+      const uint64_t key = valid ? pk[u] : 0ull;
+      const uint32_t val = valid ? pv[u] : 0u;
       const uint32_t d = (uint32_t)(((key ^ flip) >> shift) & 255u);
       uint64_t mask = __ballot(valid);
 #pragma unroll
@@ -260,6 +295,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
       if (valid && rank == 0) base[d] = pos + c;
       __builtin_amdgcn_wave_barrier();
       if (valid) { kout[pos] = key; vout[pos] = val; }
+      }
     }
     __threadfence_block();
     __syncthreads();
@@ -458,23 +494,35 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(const int4* _
   int mn[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   bool bad = false;
-  for (int e = tid; e < n; e += SS_THREADS) {
-    const int4 c = coords[e];
-    const int v[4] = {c.x, c.y, c.z, c.w};
+  for (int e0 = tid; e0 < n; e0 += 4 * SS_THREADS) {
+    int4 cc[4];  // 4 independent loads in flight per lane (clamped index: duplicates do not change min / max / or)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) { mn[f] = min(mn[f], v[f]); mx[f] = max(mx[f], v[f]); }
-    bad |= (c.x < 0) | (c.y <= -50000) | (c.y >= 50000) | (c.z <= -50000) | (c.z >= 50000) | (c.w <= -50000) |
-           (c.w >= 50000);
+    for (int u = 0; u < 4; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int4 c = cc[u];
+      const int v[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { mn[f] = min(mn[f], v[f]); mx[f] = max(mx[f], v[f]); }
+      bad |= (c.x < 0) | (c.y <= -50000) | (c.y >= 50000) | (c.z <= -50000) | (c.z >= 50000) | (c.w <= -50000) |
+             (c.w >= 50000);
+    }
   }
 #pragma unroll
   for (int f = 0; f < 4; ++f) { atomicMin(&s_mn[f], mn[f]); atomicMax(&s_mx[f], mx[f]); }
   if (bad) atomicOr(&s_bad, 1);
   __syncthreads();
   unsigned orv[4] = {0u, 0u, 0u, 0u};
-  for (int e = tid; e < n; e += SS_THREADS) {
-    const int4 c = coords[e];
-    orv[0] |= (unsigned)(c.x - s_mn[0]); orv[1] |= (unsigned)(c.y - s_mn[1]);
-    orv[2] |= (unsigned)(c.z - s_mn[2]); orv[3] |= (unsigned)(c.w - s_mn[3]);
+  for (int e0 = tid; e0 < n; e0 += 4 * SS_THREADS) {
+    int4 cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int4 c = cc[u];
+      orv[0] |= (unsigned)(c.x - s_mn[0]); orv[1] |= (unsigned)(c.y - s_mn[1]);
+      orv[2] |= (unsigned)(c.z - s_mn[2]); orv[3] |= (unsigned)(c.w - s_mn[3]);
+    }
   }
 #pragma unroll
   for (int f = 0; f < 4; ++f) atomicOr(&s_or[f], orv[f]);
@@ -489,20 +537,27 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(const int4* _
     total += w[f];
   }
   const bool compact = !s_bad && total <= 63;
-  for (int e = tid; e < n; e += SS_THREADS) {
-    const int4 c = coords[e];
-    uint64_t k;
-    if (compact) {
-      k = (uint64_t)((unsigned)(c.x - s_mn[0]) >> tz[0]);
-      k = (k << w[1]) | (uint64_t)((unsigned)(c.y - s_mn[1]) >> tz[1]);
-      k = (k << w[2]) | (uint64_t)((unsigned)(c.z - s_mn[2]) >> tz[2]);
-      k = (k << w[3]) | (uint64_t)((unsigned)(c.w - s_mn[3]) >> tz[3]);
-    } else {
-      const int64_t lin = (int64_t)c.x * 1000000000000000ll + (int64_t)c.y * 10000000000ll +
-                          (int64_t)c.z * 100000ll + (int64_t)c.w;
-      k = (uint64_t)lin ^ (1ull << 63);
+  for (int e0 = tid; e0 < n; e0 += 4 * SS_THREADS) {
+    int4 cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * SS_THREADS;
+      const int4 c = cc[u];
+      uint64_t k;
+      if (compact) {
+        k = (uint64_t)((unsigned)(c.x - s_mn[0]) >> tz[0]);
+        k = (k << w[1]) | (uint64_t)((unsigned)(c.y - s_mn[1]) >> tz[1]);
+        k = (k << w[2]) | (uint64_t)((unsigned)(c.z - s_mn[2]) >> tz[2]);
+        k = (k << w[3]) | (uint64_t)((unsigned)(c.w - s_mn[3]) >> tz[3]);
+      } else {
+        const int64_t lin = (int64_t)c.x * 1000000000000000ll + (int64_t)c.y * 10000000000ll +
+                            (int64_t)c.z * 100000ll + (int64_t)c.w;
+        k = (uint64_t)lin ^ (1ull << 63);
+      }
+      if (e < n) keys[e] = k;
     }
-    keys[e] = k;
   }
 }
 
