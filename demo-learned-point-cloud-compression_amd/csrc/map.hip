@@ -83,18 +83,36 @@ __global__ __launch_bounds__(256) void k_build_map27(
     sz[d] = pcc_spread3((uint32_t)(nz + 32768));
   }
   const uint64_t bk = (uint64_t)(uint32_t)b << 48;
+  // The 26 probes of a row are independent: their first table reads are issued together (one memory latency
+  // instead of 26 in sequence, which is what a latent-sized level with a handful of workgroups pays for), then
+  // their value reads; only a probe that met another key at its home slot walks on (load factor <= 0.5).
+  uint64_t q[27], slot[27];
+  unsigned long long got[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     const int dx = k / 9, dy = (k / 3) % 3, dz = k % 3;
-    int32_t r;
+    const bool ok = (k != 13) & okx[dx] & oky[dy] & okz[dz];
+    q[k] = bk | sx[dx] | sy[dy] | sz[dz];
+    slot[k] = hash64(q[k]) & mask;
+    got[k] = ok ? tk[slot[k]] : HASH_EMPTY;
+  }
+  int32_t r[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) r[k] = (got[k] == q[k]) ? (int32_t)tv[slot[k]] : -1;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
     if (k == 13) {
-      r = (int32_t)i;
-    } else if (okx[dx] & oky[dy] & okz[dz]) {
-      r = hash_find(tk, tv, mask, bk | sx[dx] | sy[dy] | sz[dz]);
-    } else {
-      r = -1;
+      r[k] = (int32_t)i;
+    } else if (got[k] != q[k] && got[k] != HASH_EMPTY) {  // home slot taken by another key: linear probing
+      uint64_t sl = (slot[k] + 1) & mask;
+      for (uint64_t step = 0; step < mask; ++step) {
+        const unsigned long long kk = tk[sl];
+        if (kk == q[k]) { r[k] = (int32_t)tv[sl]; break; }
+        if (kk == HASH_EMPTY) break;
+        sl = (sl + 1) & mask;
+      }
     }
-    nbr[(int64_t)k * n + i] = r;
+    nbr[(int64_t)k * n + i] = r[k];
   }
 }
 
