@@ -66,7 +66,16 @@ struct DevPool {
     size_t cap, off;
   };
   std::vector<Block> blocks;
+  // called with the stream idle.  A pool that has grown into many blocks (GOP sizes changing over time) is
+  // re-made as one block of the same total size, so the chain stays short and nothing is stranded.
   void reset() {
+    if (blocks.size() > 32) {
+      size_t total = 0;
+      for (auto& b : blocks) total += b.cap;
+      release();
+      char* p = nullptr;
+      if (hipMalloc((void**)&p, total) == hipSuccess) blocks.push_back({p, total, 0});
+    }
     for (auto& b : blocks) b.off = 0;
   }
   void* alloc(size_t bytes) {

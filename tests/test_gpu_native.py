@@ -176,3 +176,19 @@ def test_octree_one_call_entry_points(rt, oracle):
     # empty frame
     rtm.check(rt.lib.pcc_octree_encode(rt.ctx, None, 0, 9, out.ctypes.data, cap, C.byref(n_out)), "pcc_octree_encode")
     assert out[:n_out.value].tobytes() == utils.gpcc_encode(keys[:0], keys_h[:0], 0, 0, 9)
+
+
+def test_native_pool_survives_many_sizes(wl, codec):
+    """GOP sizes that keep changing make the device pool add blocks; it is re-made as one block when the chain
+    gets long, and results do not depend on the pool's history"""
+    base = [wl.sphere_shell(20, 7.5, seed=4)]
+    cb, fb = _stack(base)
+    ref, _, _ = codec.encode(cb, fb, 1, [[1, 1]])
+    for s in range(40):
+        fr = [wl.sphere_shell(14 + (s * 7) % 40, 4.0 + (s % 9), seed=s)]
+        c, f = _stack(fr)
+        out, _, _ = codec.encode(c, f, 1, [[1, 1]])
+        n = codec.decode(out[0])[0].shape[0]
+        assert n == fr[0]["points"].shape[0]
+    again, _, _ = codec.encode(cb, fb, 1, [[1, 1]])
+    assert again == ref
