@@ -192,3 +192,25 @@ def test_native_pool_survives_many_sizes(wl, codec):
         assert n == fr[0]["points"].shape[0]
     again, _, _ = codec.encode(cb, fb, 1, [[1, 1]])
     assert again == ref
+
+
+def test_native_decode_of_an_empty_gop(rt, codec):
+    """a container that announces frames without any latent point decodes to an empty cloud (or is refused with
+    a stream error) — never a crash"""
+    import struct
+    utils, native = pkg("utils"), pkg("native")
+    keys = rt.to_device(np.zeros(0, np.int64))
+    blob = utils.gpcc_encode(keys, np.zeros(0, np.uint64), 0, 0, 9)
+    for n_frames in (1, 3):
+        body = struct.pack(">idd", n_frames, 1.0, 1.0) + struct.pack(">iiii", 0, 0, 0, 0)
+        for _ in range(n_frames):
+            body += struct.pack(">iiii", len(blob), 0, 0, 0) + blob
+        try:
+            c, col, offs, q, _ = codec.decode(body)
+            assert c.shape[0] == 0 and col.shape[0] == 0
+        except native.PccError as e:
+            assert e.code in (-5, -1)
+    # and the codec still works afterwards
+    out, _, _ = codec.encode(*_stack([{"points": np.array([[1, 2, 3]], np.int16), "colors": np.array([[.1, .2, .3]])}]),
+                             1, [[1, 1]])
+    assert codec.decode(out[0])[0].shape[0] == 1
