@@ -214,3 +214,29 @@ def test_native_decode_of_an_empty_gop(rt, codec):
     out, _, _ = codec.encode(*_stack([{"points": np.array([[1, 2, 3]], np.int16), "colors": np.array([[.1, .2, .3]])}]),
                              1, [[1, 1]])
     assert codec.decode(out[0])[0].shape[0] == 1
+
+
+def test_native_decode_survives_corrupted_containers(wl, codec):
+    """seeded single-byte corruptions anywhere in a container (header, y / z streams, geometry blobs, k fields):
+    pcc_decode_gop either returns a cloud or a PccError, and the codec decodes the clean container afterwards"""
+    native = pkg("native")
+    frames = [wl.sphere_shell(20, 7.5, seed=4), wl.sphere_shell(16, 5.5, seed=5, offset=(40, 0, -8))]
+    coords, feats = _stack(frames)
+    cont, _, _ = codec.encode(coords, feats, 2, [[1, 1]])
+    clean = cont[0]
+    n_ref = codec.decode(clean)[0].shape[0]
+    rng = np.random.default_rng(1234)
+    outcomes = {"ok": 0, "error": 0}
+    for _ in range(40):
+        b = bytearray(clean)
+        pos = int(rng.integers(0, len(b)))
+        b[pos] ^= int(rng.integers(1, 256))
+        try:
+            c, col, offs, _, _ = codec.decode(bytes(b))
+            assert c.shape[0] == col.shape[0] and offs[-1] == c.shape[0]
+            outcomes["ok"] += 1
+        except native.PccError as e:
+            assert e.code < 0
+            outcomes["error"] += 1
+    assert outcomes["ok"] + outcomes["error"] == 40
+    assert codec.decode(clean)[0].shape[0] == n_ref
