@@ -211,3 +211,28 @@ def test_mfma_and_scalar_paths_agree_end_to_end(wl):
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])
     assert res[0] == res[1]
+
+
+def test_conv_kernel_families_agree_end_to_end(wl):
+    """the 32->32 layers have three interchangeable kernels — row-compacting with 64-row windows (default),
+    with 128-row windows (PCC_CONV_COMPACT=128) and dense tiles (PCC_CONV_COMPACT=0): same containers and the
+    same reconstruction, run in child processes because the switch is read once per process"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, importlib, hashlib; sys.path.insert(0, %r);"
+        "p = importlib.import_module('demo-learned-point-cloud-compression_amd');"
+        "wl = importlib.import_module('demo-learned-point-cloud-compression_amd.workloads');"
+        "e = p.CompressionPipeline([[1.0,0.0],[1,1]]); d = p.DecompressionPipeline();"
+        "o,_ = e.compress(wl.gop([wl.body(60000, seed=3), wl.sphere_shell(32, 11.2, seed=8)]));"
+        "r,_ = d.decompress(o[2]);"
+        "h = hashlib.sha256(o[1]+o[2]);"
+        "[h.update(f['points'].tobytes() + f['colors'].tobytes()) for f in r];"
+        "print(h.hexdigest())" % ROOT)
+    res = []
+    for mode in ("64", "128", "0"):
+        env = dict(os.environ, PCC_CONV_COMPACT=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(r.stdout.strip().splitlines()[-1])
+    assert res[0] == res[1] == res[2]
