@@ -219,11 +219,16 @@ def main():
             # grid of the dense-tile kernels (4 waves x 32 rows) or of the row-compacting one (1 wave x 64 rows)
             # (its grid is rounded up to a multiple of 8 workgroups for the per-XCD window order)
             grids = (((n_out + 127) // 128) * 256, ((n_out + 63) // 64) * 64, ((n_out + 63) // 64 + 7) // 8 * 8 * 64)
-            for rec in pmc["kernels"]:
-                if kname in rec["kernel"] and rec["grid_threads"] in grids:
-                    roofline["traffic"] = rec["hbm_bytes_corrected"]
-                    roofline["traffic_source"] = "profiles/pmc_latest.json: (2*FETCH_SIZE+WRITE_SIZE)*1024"
-                    break
+            recs = [r for r in pmc["kernels"] if kname in r["kernel"] and r["grid_threads"] in grids]
+            # the timed (native) engine runs the g_s convs in the form that makes the child rule book in-kernel
+            # (<.., UP=true>); the PMC passes also hold the explicit form from the op-by-op pairs count
+            fused = [r for r in recs if "true, true>" in r["kernel"]]
+            if fused and os.environ.get("PCC_CONV_UP") != "0":
+                recs = fused
+            if recs:
+                roofline["traffic"] = recs[0]["hbm_bytes_corrected"]
+                roofline["traffic_kernel"] = recs[0]["kernel"].split("(")[0]
+                roofline["traffic_source"] = "profiles/pmc_latest.json: (2*FETCH_SIZE+WRITE_SIZE)*1024"
         except (OSError, KeyError, ValueError):
             pass
         roofline.update({"kernel": f"{op}{list(dims)}", "avg_ms": avg_s * 1e3, "launches": cnt,

@@ -264,18 +264,17 @@ int nbr27_of(pcc_codec* cd, CS* s, int32_t** out) {
     if (s->n == 0) {
       // nothing to fill
     } else if (gp && gp->n > 0) {
-      if (!gp->nbr27 && gp->subset_of) {
-        CS* cand = gp->subset_of;
-        int32_t* cand_nbr;
-        PCC_TRY(nbr27_of(cd, cand, &cand_nbr));
-        CODEC_ALLOC(remap, int32_t, cand->n);
-        PCC_TRY(pcc_inverse_rows(cd->ctx, gp->keep, gp->n, cand->n, remap));
-        PCC_TRY(pcc_derive_map_up(cd->ctx, cand_nbr, cand->n, gp->keep, remap, gp->n, nbr));
-      } else {
-        int32_t* pn;
-        PCC_TRY(nbr27_of(cd, gp, &pn));
-        PCC_TRY(pcc_derive_map_up(cd->ctx, pn, gp->n, nullptr, nullptr, gp->n, nbr));
-      }
+      int32_t* pn;
+      PCC_TRY(nbr27_of(cd, gp, &pn));
+      PCC_TRY(pcc_derive_map_up(cd->ctx, pn, gp->n, nullptr, nullptr, gp->n, nbr));
+    } else if (s->subset_of && s->subset_of->gen_parent && s->subset_of->gen_parent->n > 0) {
+      // pruned level: straight from the book of the level its candidates were generated from
+      CS* cand = s->subset_of;
+      int32_t* pn;
+      PCC_TRY(nbr27_of(cd, cand->gen_parent, &pn));
+      CODEC_ALLOC(remap, int32_t, cand->n);
+      PCC_TRY(pcc_inverse_rows(cd->ctx, s->keep, s->n, cand->n, remap));
+      PCC_TRY(pcc_subset_map_up(cd->ctx, pn, cand->gen_parent->n, s->keep, remap, s->n, nbr));
     } else if (s->n > kHashBuildMax && s->stride <= 4096) {
       PCC_TRY(down_of(cd, s));
       int32_t* pn;
@@ -1135,7 +1134,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
         CS* c0;
         int32_t* nbr0;
         PCC_TRY(up_of(cd, ycs, &c0));
-        PCC_TRY(nbr27_of(cd, c0, &nbr0));
+        PCC_TRY(nbr27_of(cd, pcc_conv_up_fused() ? ycs : c0, &nbr0));
       }
       PCC_TRY(pcc_rans_decode8(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(),
                                gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p));
@@ -1165,12 +1164,19 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     PCC_TRY(wb(cd, cname, &w, &b, &tw));
     PCC_TRY(wb(cd, oname, &hw, &hb, &thw));
     const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
-    int32_t* nbr;
-    PCC_TRY(nbr27_of(cd, u.cs, &nbr));
     const int64_t nu = u.cs->n;
     CODEC_ALLOC(feats, float, std::max<int64_t>(nu, 1) * cout);
     CODEC_ALLOC(logits, float, std::max<int64_t>(nu, 1));
-    PCC_TRY(pcc_sparse_conv_head(ctx, u.f, nu, nbr, 27, nu, nu, w, b, cin, cout, 1, feats, hw, hb, logits));
+    if (pcc_conv_up_fused() && cin == 32 && cout == 32 && nu > 0) {
+      // rule book of the 8N candidates formed inside the conv from the book of the N rows below
+      int32_t* pn;
+      PCC_TRY(nbr27_of(cd, h.cs, &pn));
+      PCC_TRY(pcc_sparse_conv_head_up(ctx, u.f, h.cs->n, pn, h.cs->n, w, b, 1, feats, hw, hb, logits));
+    } else {
+      int32_t* nbr;
+      PCC_TRY(nbr27_of(cd, u.cs, &nbr));
+      PCC_TRY(pcc_sparse_conv_head(ctx, u.f, nu, nbr, 27, nu, nu, w, b, cin, cout, 1, feats, hw, hb, logits));
+    }
     const std::vector<int64_t>* offs;
     PCC_TRY(offsets_of(cd, u.cs, &offs));
     std::vector<int64_t> kj((size_t)nb), new_offs(1, 0);

@@ -69,6 +69,10 @@ struct PccProfScope {
   ~PccProfScope();
 };
 
+// True when pcc_sparse_conv_head_up has a kernel to run (the row-compacting MFMA family is selected and
+// PCC_CONV_UP=0 is not set); the whole-GOP decoder otherwise materialises the child rule books.
+bool pcc_conv_up_fused();
+
 // Reset the arena at the start of an API call.
 static inline void pcc_arena_reset(pcc_ctx* c) { c->arena_off = 0; }
 // Make sure the arena can hold `bytes` in total for this call; may

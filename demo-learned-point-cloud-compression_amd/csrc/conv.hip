@@ -411,6 +411,16 @@ static int compact_rows() {
   return v;
 }
 
+static bool conv_simple() {
+  static const bool simple = [] { const char* e = getenv("PCC_CONV_SIMPLE"); return e && e[0] == '1'; }();
+  return simple;
+}
+
+bool pcc_conv_up_fused() {
+  static const bool off = [] { const char* e = getenv("PCC_CONV_UP"); return e && e[0] == '0'; }();
+  return !off && !force_scalar() && !conv_simple() && compact_rows() != 0;
+}
+
 template <bool HEAD>
 static void launch_compact(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
                            int64_t n_out, const float* d_w, const float* d_bias, int relu, float* d_out,
@@ -439,7 +449,7 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
   const unsigned gm = nblk(n_out, 32 * GC_WAVES);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
-  static const bool simple = [] { const char* e = getenv("PCC_CONV_SIMPLE"); return e && e[0] == '1'; }();
+  const bool simple = conv_simple();
   const float* nof = nullptr;
   float* nofo = nullptr;
   if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32 && compact_rows() != 0 &&
@@ -491,6 +501,30 @@ extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_i
   // generic shapes: the two layers one after the other (same bits)
   PCC_TRY(pcc_sparse_conv(ctx, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out));
   return pcc_linear(ctx, d_out, n_out, d_head_w, d_head_b, cout, 1, 0, d_head_out);
+}
+
+extern "C" int pcc_sparse_conv_head_up(pcc_ctx* ctx, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent,
+                                       int64_t parent_pitch, const float* d_w, const float* d_bias, int relu,
+                                       float* d_out, const float* d_head_w, const float* d_head_b,
+                                       float* d_head_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv_head_up: null ctx");
+  if (n_parents <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_nbr_parent && d_w && d_bias && d_out && d_head_w && d_head_b && d_head_out &&
+                  parent_pitch >= n_parents && n_parents < ((int64_t)1 << 27),
+              PCC_E_ARG, "pcc_sparse_conv_head_up: bad buffers (pitch %lld, parents %lld)", (long long)parent_pitch,
+              (long long)n_parents);
+  PCC_REQUIRE((uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0, PCC_E_ARG,
+              "pcc_sparse_conv_head_up: feature rows must be 16-byte aligned");
+  PCC_REQUIRE(pcc_conv_up_fused(), PCC_E_ARG,
+              "pcc_sparse_conv_head_up: only the row-compacting MFMA kernel has this form (PCC_FORCE_SCALAR / "
+              "PCC_CONV_SIMPLE / PCC_CONV_COMPACT=0 / PCC_CONV_UP=0 select the explicit rule book: pcc_derive_map_up)");
+  const int64_t n_out = 8 * n_parents;
+  PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
+  hipLaunchKernelGGL((k_gconv_mfma_compact<1, true, true>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0,
+                     ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
+                     d_head_b, d_head_out);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
 }
 
 extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, const float* d_w,

@@ -41,7 +41,11 @@
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int RCH, bool HEAD>
+// UP: the rows are the 8 generative children (row 8p + o) of the rows of a PARENT level and `nbr` / `pitch` are
+// the parent level's rule book: the child's neighbour at offset k is child o' of parent-neighbour kp (per axis
+// t = o + d, D = floor(t / 2), o' = t & 1 — pcc_derive_map_up's rule), formed here from one parent-book load, so
+// the 27 x 8N child rule book is never written to or read from HBM.
+template <int RCH, bool HEAD, bool UP = false>
 __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
@@ -77,8 +81,19 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
 #pragma unroll
     for (int c = 0; c < RCH; ++c) {  // branch-free (clamped address + select): keeps the loads out of control flow
       const int64_t r = row0 + c * 64 + lane;
-      const int32_t v = nbr[(int64_t)(k < k_vol ? k : k_vol - 1) * pitch + (r < n_out ? r : n_out - 1)];
-      nbreg[c] = (k < k_vol && r < n_out) ? v : -1;
+      const int kk = k < k_vol ? k : k_vol - 1;
+      const int64_t rc = r < n_out ? r : n_out - 1;
+      if constexpr (UP) {
+        const int o = (int)(rc & 7);
+        const int tx = ((o >> 2) & 1) + (kk / 9) - 1, ty = ((o >> 1) & 1) + ((kk / 3) % 3) - 1, tz = (o & 1) + (kk % 3) - 1;
+        const int kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
+        const int op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+        const int32_t pr = nbr[(int64_t)kp * pitch + (rc >> 3)];
+        nbreg[c] = (k < k_vol && r < n_out && pr >= 0) ? ((pr << 3) | op) : -1;
+      } else {
+        const int32_t v = nbr[(int64_t)kk * pitch + rc];
+        nbreg[c] = (k < k_vol && r < n_out) ? v : -1;
+      }
     }
   };
   // pack the rows that have the offset held in nbreg into slot lists `b`; returns their count

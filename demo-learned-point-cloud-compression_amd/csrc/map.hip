@@ -159,6 +159,33 @@ __global__ __launch_bounds__(256) void k_derive_up(const int32_t* __restrict__ n
   }
 }
 
+// Rule book of a PRUNED level straight from the rule book of the level its candidates were generated from:
+// pruned row j is candidate c = keep[j] = child o of parent p; its neighbour at offset k is the candidate
+// (nbr_p[kp][p] << 3 | o'), which maps to the pruned row remap[candidate] or -1.  The candidate level's own
+// 27 x 8N rule book never exists.
+__global__ __launch_bounds__(256) void k_subset_map_up(const int32_t* __restrict__ nbr_p, int64_t pitch_p,
+                                                       const uint32_t* __restrict__ keep,
+                                                       const int32_t* __restrict__ remap, int64_t n_keep,
+                                                       int32_t* __restrict__ nbr) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_keep) return;
+  const uint32_t c = keep[j];
+  const int64_t p = c >> 3;
+  const int o = (int)(c & 7u);
+  int32_t pr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {  // the 27 parent-book reads are independent: issue them together
+    int kp, op;
+    child_step(o, k, &kp, &op);
+    const int32_t q = nbr_p[(int64_t)kp * pitch_p + p];
+    pr[k] = q < 0 ? -1 : ((q << 3) | op);
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) pr[k] = pr[k] < 0 ? -1 : remap[pr[k]];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) nbr[(int64_t)k * n_keep + j] = pr[k];
+}
+
 // children given by a stride-2 map (parent_of, nbr8): second lookup through nbr8
 __global__ __launch_bounds__(256) void k_derive_down(const int32_t* __restrict__ nbr_p, int64_t n_par,
                                                      const int32_t* __restrict__ nbr8,
@@ -199,6 +226,19 @@ extern "C" int pcc_derive_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent, int6
   PccProfScope prof(ctx, "derive_map_up", n_parents * 8, parent_pitch, d_remap ? 1 : 0, 27);
   hipLaunchKernelGGL(k_derive_up, dim3(nblk(n_parents * 8, 256)), dim3(256), 0, ctx->stream, d_nbr_parent,
                      parent_pitch, d_parent_rows, d_remap, n_parents, d_nbr);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_subset_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t parent_pitch,
+                                 const uint32_t* d_keep, const int32_t* d_remap, int64_t n_keep, int32_t* d_nbr) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_subset_map_up: null ctx");
+  if (n_keep <= 0) return PCC_OK;
+  PCC_REQUIRE(d_nbr_parent && d_keep && d_remap && d_nbr && parent_pitch >= 1, PCC_E_ARG,
+              "pcc_subset_map_up: bad buffers");
+  PccProfScope prof(ctx, "subset_map_up", n_keep, parent_pitch, 0, 27);
+  hipLaunchKernelGGL(k_subset_map_up, dim3(nblk(n_keep, 256)), dim3(256), 0, ctx->stream, d_nbr_parent,
+                     parent_pitch, d_keep, d_remap, n_keep, d_nbr);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

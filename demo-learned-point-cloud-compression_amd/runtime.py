@@ -228,6 +228,14 @@ class Runtime:
                                          _ptr(nbr)), "pcc_derive_map_up")
         return nbr
 
+    def subset_map_up(self, nbr_parent, keep, remap):
+        """rule book [27, n_keep] of the rows `keep` of the 8 n generative children of a level with book nbr_parent"""
+        n_keep = keep.shape[0]
+        nbr = self.empty((27, n_keep), torch.int32)
+        check(self.lib.pcc_subset_map_up(self.ctx, _ptr(nbr_parent), nbr_parent.stride(0), _ptr(keep), _ptr(remap),
+                                         n_keep, _ptr(nbr)), "pcc_subset_map_up")
+        return nbr
+
     def derive_map_down(self, nbr_parent, nbr8, parent_of, keys, child_shift):
         n = keys.shape[0]
         nbr = self.empty((27, n), torch.int32)
@@ -287,6 +295,18 @@ class Runtime:
         check(self.lib.pcc_sparse_conv_head(self.ctx, _ptr(x), x.shape[0], _ptr(nbr), k_vol, nbr.stride(0), n_out,
                                             _ptr(w), _ptr(b), cin, cout, 1 if relu else 0, _ptr(out),
                                             _ptr(head_w), _ptr(head_b), _ptr(logits)), "pcc_sparse_conv_head")
+        return out, logits
+
+    def sparse_conv_head_up(self, x, nbr_parent, w, b, relu, head_w, head_b):
+        """sparse_conv_head on the 8 n generative children of a level, given THAT level's rule book [27, n]:
+        the child rule book is formed inside the kernel (same bits as derive_map_up + sparse_conv_head)"""
+        n_parents = nbr_parent.shape[1]
+        assert x.shape == (8 * n_parents, 32) and w.shape == (27, 32, 32) and head_w.numel() == 32
+        out = self.empty((8 * n_parents, 32), torch.float32)
+        logits = self.empty((8 * n_parents,), torch.float32)
+        check(self.lib.pcc_sparse_conv_head_up(self.ctx, _ptr(x), n_parents, _ptr(nbr_parent), nbr_parent.stride(0),
+                                               _ptr(w), _ptr(b), 1 if relu else 0, _ptr(out), _ptr(head_w),
+                                               _ptr(head_b), _ptr(logits)), "pcc_sparse_conv_head_up")
         return out, logits
 
     def convT_gen(self, x, w, b, relu):

@@ -200,6 +200,26 @@ int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                          int cin, int cout, int relu, float* d_out,
                          const float* d_head_w, const float* d_head_b,
                          float* d_head_out);
+/* The g_s stage form of the two above with the rule book formed on the fly.
+ * The conv3 of a synthesis stage runs on the 8 generative children (row 8p+o) of
+ * the n_parents rows of the level below; d_nbr_parent is THAT level's 27-offset
+ * rule book ([27, parent_pitch]), and the child rule book (27 x 8 n_parents
+ * int32, 352 MB for the bench frame) is never materialised: same values as
+ * pcc_derive_map_up(parent book) followed by pcc_sparse_conv_head, bit for bit.
+ * cin = cout = 32, K = 27 only (the shape of the model's g_s stages).
+ * pcc_subset_map_up gives the rule book of the level that survives the top-k
+ * pruning of those children (rows d_keep, ascending; d_remap from
+ * pcc_inverse_rows over the 8 n_parents candidates), again from the parent
+ * book: d_nbr is [27, n_keep]. */
+int pcc_sparse_conv_head_up(pcc_ctx* ctx, const float* d_in, int64_t n_parents,
+                            const int32_t* d_nbr_parent, int64_t parent_pitch,
+                            const float* d_w, const float* d_bias, int relu,
+                            float* d_out, const float* d_head_w,
+                            const float* d_head_b, float* d_head_out);
+int pcc_subset_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent,
+                      int64_t parent_pitch, const uint32_t* d_keep,
+                      const int32_t* d_remap, int64_t n_keep, int32_t* d_nbr);
+
 /* replaces: MinkowskiGenerativeConvolutionTranspose forward (kernel 2,
  * stride 2): out[8p+o] = W[o]^T in[p] + bias. */
 int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in,

@@ -216,7 +216,9 @@ def test_mfma_and_scalar_paths_agree_end_to_end(wl):
 def test_conv_kernel_families_agree_end_to_end(wl):
     """the 32->32 layers have three interchangeable kernels — row-compacting with 64-row windows (default),
     with 128-row windows (PCC_CONV_COMPACT=128) and dense tiles (PCC_CONV_COMPACT=0): same containers and the
-    same reconstruction, run in child processes because the switch is read once per process"""
+    same reconstruction, run in child processes because the switch is read once per process; the default decoder
+    also forms the g_s candidate rule books inside the conv (pcc_sparse_conv_head_up), PCC_CONV_UP=0 and
+    PCC_CONV_COMPACT=0 materialise them"""
     import subprocess
     import sys
     code = (
@@ -230,9 +232,9 @@ def test_conv_kernel_families_agree_end_to_end(wl):
         "[h.update(f['points'].tobytes() + f['colors'].tobytes()) for f in r];"
         "print(h.hexdigest())" % ROOT)
     res = []
-    for mode in ("64", "128", "0"):
-        env = dict(os.environ, PCC_CONV_COMPACT=mode)
+    for mode in ("64", "128", "0", "up0"):  # up0: 64-row windows with the explicit child rule books
+        env = dict(os.environ, PCC_CONV_UP="0") if mode == "up0" else dict(os.environ, PCC_CONV_COMPACT=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])
-    assert res[0] == res[1] == res[2]
+    assert res[0] == res[1] == res[2] == res[3]

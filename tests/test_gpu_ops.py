@@ -289,6 +289,68 @@ def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
     assert np.array_equal(host(logits), oracle.linear(refr, hw, hb)[:, 0])
 
 
+@pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 500, 2100])
+def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
+    """pcc_sparse_conv_head_up: conv on the 8N generative children given only the parents' rule book, against
+    the oracle's conv over the hashed child rule book; pcc_subset_map_up: the rule book of a pruned subset of
+    those children against the oracle's hash build over the kept keys"""
+    rng = np.random.default_rng(77 + n)
+    pts = _structured_cloud(kind, n) * 2
+    pkeys = sorted_keys(oracle, pts)                       # stride-2 parents
+    nbr_p = oracle.map27(pkeys, 2)
+    ckeys = oracle.up(pkeys, 2)                            # row 8p + o
+    nbr_c = oracle.map27(ckeys, 1)
+    x = rng.normal(size=(len(ckeys), 32)).astype(np.float32)
+    w, b = _weights(rng, 27, 32, 32)
+    hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
+    hb = rng.normal(0, 0.1, 1).astype(np.float32)
+    ref = oracle.sparse_conv(x, nbr_c, w, b, True)
+    feats, logits = rt.sparse_conv_head_up(dev(rt, x), dev(rt, nbr_p), dev(rt, w), dev(rt, b), True, dev(rt, hw),
+                                           dev(rt, hb))
+    assert np.array_equal(host(feats), ref)
+    assert np.array_equal(host(logits), oracle.linear(ref, hw, hb)[:, 0])
+    # a pitch wider than the parent count must be honoured
+    wide = np.full((27, len(pkeys) + 5), -1, np.int32)
+    wide[:, :len(pkeys)] = nbr_p
+    rtm = pkg("runtime")
+    xd, wide_d, wd, bd, hwd, hbd = dev(rt, x), dev(rt, wide), dev(rt, w), dev(rt, b), dev(rt, hw), dev(rt, hb)
+    f2 = rt.empty((len(ckeys), 32), torch.float32)
+    l2 = rt.empty((len(ckeys),), torch.float32)
+    rtm.check(rt.lib.pcc_sparse_conv_head_up(rt.ctx, rtm._ptr(xd), len(pkeys), rtm._ptr(wide_d), wide.shape[1],
+                                             rtm._ptr(wd), rtm._ptr(bd), 1, rtm._ptr(f2), rtm._ptr(hwd),
+                                             rtm._ptr(hbd), rtm._ptr(l2)), "pcc_sparse_conv_head_up")
+    assert np.array_equal(host(f2), ref)
+
+    keep = np.sort(rng.choice(len(ckeys), size=max(1, len(ckeys) // 3), replace=False)).astype(np.uint32)
+    keep_d = dev(rt, keep.view(np.int32))
+    remap = rt.inverse_rows(keep_d, len(ckeys))
+    got = host(rt.subset_map_up(dev(rt, nbr_p), keep_d, remap))
+    assert np.array_equal(got, oracle.map27(ckeys[keep], 1))
+
+
+def test_conv_head_up_refuses_when_family_is_off(rt):
+    """the fused form exists only in the row-compacting MFMA family: any other selection must be refused,
+    not silently computed by something else"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, importlib, torch; sys.path.insert(0, %r)\n"
+            "p = importlib.import_module('demo-learned-point-cloud-compression_amd')\n"
+            "rtm = importlib.import_module('demo-learned-point-cloud-compression_amd.runtime')\n"
+            "rt = rtm.Runtime()\n"
+            "x = torch.zeros((8, 32), device='cuda'); nb = torch.full((27, 1), -1, dtype=torch.int32, device='cuda')\n"
+            "w = torch.zeros((27, 32, 32), device='cuda'); b = torch.zeros(32, device='cuda')\n"
+            "hw = torch.zeros((32, 1), device='cuda'); hb = torch.zeros(1, device='cuda')\n"
+            "try:\n    rt.sparse_conv_head_up(x, nb, w, b, True, hw, hb)\n"
+            "except rtm.PccError as e:\n    print('REFUSED', e.code)\nelse:\n    print('RAN')\n") % root
+    for env, want in (({"PCC_FORCE_SCALAR": "1"}, "REFUSED"), ({"PCC_CONV_UP": "0"}, "REFUSED"),
+                      ({"PCC_CONV_COMPACT": "0"}, "REFUSED"), ({}, "RAN")):
+        out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
+                             timeout=300)
+        assert want in out.stdout, (env, out.stdout, out.stderr[-400:])
+
+
 def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):
     """n_in != n_out (stride-2 conv: 8 offsets, input = children, output = parents) and a rule book whose
     row pitch is larger than n_out: the kernel must honour the pitch and never read past n_out"""
