@@ -122,9 +122,30 @@ def main():
         rec, dside = dec.decompress(out[q_dec])
         return out, side, rec, dside
 
-    for _ in range(args.warmup):
+    def prof_table(rts, n_steps):
+        recs = []
+        for r in rts:
+            recs += r.prof_records()
+            r.prof_enable(False)
+        groups = {}
+        for op, ms, dims in recs:
+            g = groups.setdefault((op, dims), [0, 0.0])
+            g[0] += 1
+            g[1] += ms
+        return sorted(groups.items(), key=lambda kv: -kv[1][1]), sum(v[1] for v in groups.values()) / n_steps
+
+    # warm-up; its last step (untimed) runs with an event pair around EVERY C-ABI call: the per-op table below
+    # and the choice of the dominant kernel come from it
+    rts = enc.runtimes + dec.runtimes
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            for r in rts:
+                r.prof_enable(True, reserve=400)
         out, side, rec, dside = step()
     assert rec[0]["points"].shape[0] == n_pts
+    torch.cuda.synchronize()
+    table_all, sum_all = prof_table(rts, 1)
+    layer_all = [(k, v) for k, v in table_all if k[0] in ("sparse_conv", "convT_gen")]
 
     def fence():
         torch.cuda.synchronize()
@@ -132,8 +153,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for r in enc.runtimes + dec.runtimes:
-        r.prof_enable(True, reserve=160 * (args.steps + 1))
+    # timed region: only the dominant kernel is bracketed (one event pair per step); bracketing all ~150 calls
+    # of a step costs the step ~0.5 ms of stream bubbles
+    if layer_all:
+        (dom_op, dom_dims), _ = layer_all[0]
+        for r in rts:
+            r.prof_enable(True, reserve=8 * (args.steps + 1), only=dom_op, rows=dom_dims[0])
     fence()
     t_start = time.perf_counter()
     enc_ms, dec_ms = [], []
@@ -148,23 +173,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-launch records of the timed region (HIP events on the ctx streams)
-    recs = []
-    for r in enc.runtimes + dec.runtimes:
-        recs += r.prof_records()
-        r.prof_enable(False)
-    groups = {}
-    for op, ms, dims in recs:
-        g = groups.setdefault((op, dims), [0, 0.0])
-        g[0] += 1
-        g[1] += ms
-    table = sorted(groups.items(), key=lambda kv: -kv[1][1])
+    # ---- launches of the dominant kernel inside the timed region (HIP events on the ctx streams)
+    table, _ = prof_table(rts, args.steps)
+    table = [kv for kv in table if layer_all and kv[0] == (dom_op, dom_dims)]
     if rank == 0:
-        log("per-op device time over the timed region (HIP events):")
-        for (op, dims), (cnt, tot) in table[:25]:
+        log("per-op device time of the last warm-up step (HIP events around every C-ABI call):")
+        for (op, dims), (cnt, tot) in table_all[:25]:
             log(f"  {op:14s} {str(dims):34s} x{cnt:4d}  total {tot:9.3f} ms  avg {tot / cnt:8.4f} ms")
-        log(f"  sum of recorded ops per step: {sum(v[1] for v in groups.values()) / args.steps:.3f} ms; "
-            f"wall per step {1e3 * elapsed / args.steps:.3f} ms (enc {np.mean(enc_ms):.2f} + dec {np.mean(dec_ms):.2f})")
+        log(f"  sum of recorded ops of that step: {sum_all:.3f} ms; "
+            f"timed region: wall per step {1e3 * elapsed / args.steps:.3f} ms (enc {np.mean(enc_ms):.2f} + dec {np.mean(dec_ms):.2f})")
         st = side["enc_time_measurements"]
         log("  encode stages ms:", {k: (round(1e3 * v, 3) if not isinstance(v, list) else [round(1e3 * x, 3) for x in v])
                                     for k, v in st.items()})
@@ -172,7 +189,7 @@ def main():
 
     # ---- roofline of the dominant kernel (largest total device time among the layer kernels)
     roofline = None
-    layer_ops = [(k, v) for k, v in table if k[0] in ("sparse_conv", "convT_gen")]
+    layer_ops = table
     if layer_ops and rank == 0:
         (op, dims), (cnt, tot) = layer_ops[0]
         avg_s = tot / cnt / 1e3

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "pcc_timer_stop": (i32, [vp]),
     "pcc_timer_elapsed_ms": (i32, [vp, pf32]),
     "pcc_prof_enable": (i32, [vp, i32]),
+    "pcc_prof_only": (i32, [vp, C.c_char_p, i64]),
     "pcc_prof_count": (i32, [vp]),
     "pcc_prof_get": (i32, [vp, i32, C.c_char_p, i32, pf32, pi64]),
     "pcc_count_nonneg": (i32, [vp, vp, i64, pi64]),

@@ -51,6 +51,8 @@ struct pcc_ctx {
   // per-launch profiler (bench.py roofline figure): event pairs around the
   // kernels of an API call, read back after a synchronise
   bool prof_on;
+  char prof_only[32];  // "" = every entry point, else only ops whose name starts with this
+  int64_t prof_only_d0;  // and, when >= 0, whose first dimension (rows) is this
   int prof_n, prof_cap;
   struct pcc_prof_rec* prof;
 };

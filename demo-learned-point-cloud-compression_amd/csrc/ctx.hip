@@ -122,6 +122,8 @@ void* pcc_arena_alloc(pcc_ctx* c, size_t bytes) {
 PccProfScope::PccProfScope(pcc_ctx* ctx, const char* op, int64_t d0, int64_t d1, int64_t d2, int64_t d3)
     : c(ctx), slot(-1) {
   if (!c || !c->prof_on) return;
+  if (c->prof_only[0] && strncmp(op, c->prof_only, strlen(c->prof_only)) != 0) return;
+  if (c->prof_only[0] && c->prof_only_d0 >= 0 && d0 != c->prof_only_d0) return;
   if (c->prof_n == c->prof_cap) {
     const int ncap = c->prof_cap ? c->prof_cap * 2 : 256;
     pcc_prof_rec* np = (pcc_prof_rec*)realloc(c->prof, sizeof(pcc_prof_rec) * (size_t)ncap);
@@ -166,6 +168,13 @@ extern "C" int pcc_prof_enable(pcc_ctx* c, int on) {
         PCC_HIP(hipEventCreate(&c->prof[i].e1));
       }
   c->prof_on = on != 0;
+  return PCC_OK;
+}
+
+extern "C" int pcc_prof_only(pcc_ctx* c, const char* h_op_prefix, int64_t d0) {
+  PCC_REQUIRE(c, PCC_E_ARG, "null ctx");
+  snprintf(c->prof_only, sizeof(c->prof_only), "%s", h_op_prefix ? h_op_prefix : "");
+  c->prof_only_d0 = d0;
   return PCC_OK;
 }
 

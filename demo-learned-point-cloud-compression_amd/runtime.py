@@ -131,8 +131,11 @@ class Runtime:
         return ms.value
 
     # ------------------------------------------------------------ per-launch profiler
-    def prof_enable(self, on=True, reserve=0):
-        """reserve > 1 pre-creates that many event pairs (keeps event creation out of the timed region)"""
+    def prof_enable(self, on=True, reserve=0, only=None, rows=-1):
+        """reserve > 1 pre-creates that many event pairs (keeps event creation out of the timed region);
+        only / rows: bracket just the entry points whose op name starts with `only` (and whose output row
+        count is `rows`) — every event pair is a few microseconds of bubble on the stream"""
+        check(self.lib.pcc_prof_only(self.ctx, only.encode() if only else None, int(rows)), "pcc_prof_only")
         check(self.lib.pcc_prof_enable(self.ctx, max(int(reserve), 1) if on else 0), "pcc_prof_enable")
 
     def prof_records(self):

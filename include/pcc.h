@@ -86,6 +86,11 @@ int pcc_timer_elapsed_ms(pcc_ctx* ctx, float* h_ms);
  * sparse_conv: n_out, cin, cout, k_vol).  Used by bench.py for the roofline
  * figure of the dominant kernel. */
 int pcc_prof_enable(pcc_ctx* ctx, int on);
+/* restrict the records to entry points whose op name starts with the prefix
+ * ("sparse_conv", "convT_gen", ...; NULL or "" = all) and, when d0 >= 0, whose
+ * first recorded dimension (output rows) equals d0.  An event pair costs a few
+ * microseconds of stream bubble, so a timed run brackets only what it reads. */
+int pcc_prof_only(pcc_ctx* ctx, const char* h_op_prefix, int64_t d0);
 int pcc_prof_count(pcc_ctx* ctx);
 int pcc_prof_get(pcc_ctx* ctx, int i, char* h_op, int cap, float* h_ms,
                  int64_t* h_dims);
