@@ -44,6 +44,7 @@ PROTOTYPES = {
     "pcc_decode_gop": (i32, [vp, vp, i64, C.POINTER(PccCloudInfo), C.POINTER(C.c_double)]),
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
     "pcc_sparse_conv_head_up": (i32, [vp, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp, vp]),
+    "pcc_exclusive_scan_u32": (i32, [vp, vp, vp, i64, vp]),
     "pcc_subset_map_up": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "pcc_octree_encode": (i32, [vp, vp, i64, i32, vp, i64, pi64]),
     "pcc_octree_decode": (i32, [vp, i64, vp, i64, pi64]),

@@ -83,35 +83,54 @@ __global__ __launch_bounds__(256) void k_build_map27(
     sz[d] = pcc_spread3((uint32_t)(nz + 32768));
   }
   const uint64_t bk = (uint64_t)(uint32_t)b << 48;
-  // The 26 probes of a row are independent: their first table reads are issued together (one memory latency
-  // instead of 26 in sequence, which is what a latent-sized level with a handful of workgroups pays for), then
-  // their value reads; only a probe that met another key at its home slot walks on (load factor <= 0.5).
-  uint64_t q[27], slot[27];
-  unsigned long long got[27];
+  // The 26 probes of a row are independent: their table reads are issued together, round by round (home slot,
+  // +1, +2, ... until no lane of the wave has a probe pending): one memory latency per round instead of one per
+  // probe step per offset — with 1728 probes per wave some probe of nearly every offset runs long, so walking
+  // offset by offset cost the latent-sized levels (a handful of workgroups) 27 serial chains.  Later rounds read
+  // all 27 slots unconditionally so that they stay batched; the table is sized for a load factor <= 0.25.
+  uint64_t q[27];
+  uint32_t slot[27];
+  uint32_t pend = 0, hit = 0;  // bit k: still searching / found at slot[k]
+  {
+    unsigned long long got[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int dx = k / 9, dy = (k / 3) % 3, dz = k % 3;
-    const bool ok = (k != 13) & okx[dx] & oky[dy] & okz[dz];
-    q[k] = bk | sx[dx] | sy[dy] | sz[dz];
-    slot[k] = hash64(q[k]) & mask;
-    got[k] = ok ? tk[slot[k]] : HASH_EMPTY;
+    for (int k = 0; k < 27; ++k) {
+      const int dx = k / 9, dy = (k / 3) % 3, dz = k % 3;
+      const bool ok = (k != 13) & okx[dx] & oky[dy] & okz[dz];
+      q[k] = bk | sx[dx] | sy[dy] | sz[dz];
+      slot[k] = (uint32_t)(hash64(q[k]) & mask);
+      got[k] = ok ? tk[slot[k]] : HASH_EMPTY;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      if (got[k] == q[k]) hit |= 1u << k;
+      else if (got[k] != HASH_EMPTY) pend |= 1u << k;
+    }
+  }
+  for (uint32_t rd = 1; rd <= (uint32_t)mask && __any(pend != 0); ++rd) {  // wave-uniform
+    unsigned long long got[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) got[k] = tk[(slot[k] + rd) & (uint32_t)mask];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      if ((pend >> k) & 1u) {
+        if (got[k] == q[k]) {
+          hit |= 1u << k;
+          pend &= ~(1u << k);
+          slot[k] = (slot[k] + rd) & (uint32_t)mask;
+        } else if (got[k] == HASH_EMPTY) {
+          pend &= ~(1u << k);
+        }
+      }
+    }
   }
   int32_t r[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) r[k] = (got[k] == q[k]) ? (int32_t)tv[slot[k]] : -1;
+  for (int k = 0; k < 27; ++k) r[k] = (int32_t)tv[slot[k]];  // unconditional: batched; slot[k] is always in range
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    if (k == 13) {
-      r[k] = (int32_t)i;
-    } else if (got[k] != q[k] && got[k] != HASH_EMPTY) {  // home slot taken by another key: linear probing
-      uint64_t sl = (slot[k] + 1) & mask;
-      for (uint64_t step = 0; step < mask; ++step) {
-        const unsigned long long kk = tk[sl];
-        if (kk == q[k]) { r[k] = (int32_t)tv[sl]; break; }
-        if (kk == HASH_EMPTY) break;
-        sl = (sl + 1) & mask;
-      }
-    }
+    if (k == 13) r[k] = (int32_t)i;
+    else if (!((hit >> k) & 1u)) r[k] = -1;
     nbr[(int64_t)k * n + i] = r[k];
   }
 }
@@ -274,7 +293,7 @@ extern "C" int pcc_inverse_rows(pcc_ctx* ctx, const uint32_t* d_rows, int64_t m,
 
 static int64_t hash_capacity(int64_t n) {
   int64_t cap = 1024;
-  while (cap < 2 * n) cap <<= 1;
+  while (cap < 4 * n) cap <<= 1;  // load factor <= 0.25: short probe sequences (the rounds of k_build_map27)
   return cap;
 }
 

@@ -48,89 +48,158 @@ __global__ void k_oct_leaves(const uint64_t* __restrict__ keys, int64_t n, int s
   if (i < n) leaves[i] = (keys[i] >> shift) & mask;
 }
 
-// ---- single-workgroup form (n <= OCT_SMALL_MAX): every level in one launch -----------------
-// Latent frames are ~1e3..3e4 leaves; the per-level launches above are pure launch latency for
-// them.  One 1024-thread block walks the levels bottom-up; per level it counts the parents
-// (block reduce), then scans tile by tile with a running carry and emits parents + occupancy
-// bytes.  Levels are packed back to front in `occ` so that the finished array is contiguous
-// root-first and ends at occ + cap.
+// ---- single-workgroup form (n <= OCT_SMALL_MAX): every level in one launch, from the leaves alone -----------
+// Latent frames are ~1e3..3e4 leaves; per-level launches are pure launch latency for them, and walking the
+// levels bottom-up inside one workgroup still pays a dependent global round trip per level (117 us for the
+// bench latent).  All levels follow from the sorted leaves directly: with h = the highest bit in which leaf e
+// differs from leaf e-1, e opens a new node at every level L with 3 (depth - L) <= h, i.e. L >= lmin(e) =
+// depth - h / 3 (leaf 0 opens one everywhere).  So
+//   nodes at level L          = #{e : lmin(e) <= L}
+//   node of leaf e at level L = #{e' <= e : lmin(e') <= L} - 1
+// and the leaf that opens a node at level L+1 sets bit (leaf >> 3 (depth-L-1)) & 7 in its level-L node.
+// Sweep 1 histograms lmin (level counts -> offsets of the root-first packed array); sweep 2 ranks the leaves
+// per level with wave ballots (one per level per 64 leaves) and ORs the bits in.
 #define OCT_SMALL_MAX 65536
 #define OCT_T 1024
+#define OCT_W (OCT_T / 64)
+#define OCT_MAXD 16
+#define OCT_LDS_WORDS 24576
+#define OCT_U 8
 
-__device__ __forceinline__ uint32_t oct_block_scan(uint32_t v, uint32_t* total, uint32_t* s_w) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < OCT_T / 64; ++w) {
-    const uint32_t s = s_w[w];
-    if (w < wave) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
+__device__ __forceinline__ int oct_lmin(uint64_t prev, uint64_t cur, bool first, int depth) {
+  if (first) return 0;
+  const uint64_t x = prev ^ cur;
+  if (x == 0) return depth + 1;  // repeated leaf: opens nothing, not even a leaf
+  return depth - (63 - __builtin_clzll(x)) / 3;
 }
 
 __global__ __launch_bounds__(OCT_T) void k_oct_small(const uint64_t* __restrict__ keys, int n, int shift,
-                                                     uint64_t mask, int depth, uint64_t* __restrict__ buf_a,
-                                                     uint64_t* __restrict__ buf_b, uint8_t* __restrict__ occ,
+                                                     uint64_t mask, int depth, uint32_t* __restrict__ occ32,
                                                      int cap, uint32_t* __restrict__ counts) {
-  __shared__ uint32_t s_w[OCT_T / 64];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < n; e += OCT_T) buf_a[e] = (keys[e] >> shift) & mask;
-  __threadfence_block();
-  __syncthreads();
-  uint64_t* cur = buf_a;
-  uint64_t* nxt = buf_b;
-  int n_cur = n, end = cap;
-  if (tid == 0) counts[depth] = (uint32_t)n;
-  for (int L = depth - 1; L >= 0; --L) {
-    // pass A: number of parents
-    uint32_t c = 0;
-    for (int e = tid; e < n_cur; e += OCT_T) c += (e == 0 || (cur[e - 1] >> 3) != (cur[e] >> 3)) ? 1u : 0u;
-    uint32_t m;
-    oct_block_scan(c, &m, s_w);
-    const int base_out = end - (int)m;
-    // pass B: scan tiles with a carry, emit
-    uint32_t carry = 0;
-    for (int t0 = 0; t0 < n_cur; t0 += OCT_T) {
-      const int e = t0 + tid;
-      uint32_t f = 0;
-      uint64_t pk = 0;
-      if (e < n_cur) {
-        pk = cur[e] >> 3;
-        f = (e == 0 || (cur[e - 1] >> 3) != pk) ? 1u : 0u;
+  // Each wave owns a contiguous chunk of leaves in both sweeps, so after the one exchange of per-wave level
+  // counts the waves never wait for each other and their loads overlap.
+  __shared__ uint32_t s_off[OCT_MAXD + 1];
+  __shared__ uint32_t s_wcnt[OCT_W][OCT_MAXD + 4];  // [wave][v]: leaves of the chunk with lmin == v
+  __shared__ uint32_t s_run[OCT_W][OCT_MAXD];       // [wave][L]: level-L nodes opened before the wave's chunk
+  // the occupancy bytes are assembled in LDS when they fit (a latent has ~1.3 bytes per leaf): ORing them into
+  // HBM costs one L2 atomic transaction per node, ~10 ns each from a single CU (measured: 310 us for 35k nodes)
+  __shared__ uint32_t s_occ[OCT_LDS_WORDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lanes_le = ~0ull >> (63 - lane);
+  const int chunk = ((n + OCT_W - 1) / OCT_W + 63) & ~63;
+  const int c0 = min(wave * chunk, n), c1 = min(c0 + chunk, n);
+
+  // sweep 1: per-wave histogram of lmin, counted per lane in 16-bit fields (a lane sees <= chunk / 64 <= 64 leaves
+  // of a 65536-leaf input; a wave total <= 4096 still fits) and summed across the wave once
+  unsigned long long f[5] = {0ull, 0ull, 0ull, 0ull, 0ull};  // field v lives in f[v >> 2], bits 16 (v & 3)
+  // OCT_U x 64 leaves in flight per wave (one workgroup has nobody else to hide the latency behind); the previous
+  // leaf comes from the neighbouring lane, across steps from lane 63 of the step before
+  const uint64_t k_before = c0 < c1 ? (keys[max(c0 - 1, 0)] >> shift) & mask : 0ull;
+  uint64_t tail = k_before;
+  for (int e0 = c0; e0 < c1; e0 += 64 * OCT_U) {  // wave-uniform
+    uint64_t kc[OCT_U];
+#pragma unroll
+    for (int u = 0; u < OCT_U; ++u) kc[u] = (keys[min(e0 + u * 64 + lane, n - 1)] >> shift) & mask;
+#pragma unroll
+    for (int u = 0; u < OCT_U; ++u) {
+      const int e = e0 + u * 64 + lane;
+      const uint64_t up = __shfl_up((unsigned long long)kc[u], 1, 64);
+      const uint64_t kp = lane == 0 ? tail : up;
+      tail = __shfl((unsigned long long)kc[u], 63, 64);
+      if (e < c1) {
+        const int lm = oct_lmin(kp, kc[u], e == 0, depth);  // 0 .. depth + 1 <= 17
+        const unsigned long long one = 1ull << (16 * (lm & 3));
+#pragma unroll
+        for (int w = 0; w < 5; ++w) f[w] += (lm >> 2) == w ? one : 0ull;
       }
-      uint32_t tile_tot;
-      const uint32_t ex = oct_block_scan(f, &tile_tot, s_w);
-      if (f) {
-        uint32_t byte = 0;
-        for (int j = e; j < n_cur && j < e + 8; ++j) {
-          const uint64_t k = cur[j];
-          if ((k >> 3) != pk) break;
-          byte |= 1u << (uint32_t)(k & 7ull);
-        }
-        const uint32_t p = carry + ex;
-        nxt[p] = pk;
-        occ[base_out + (int)p] = (uint8_t)byte;
-      }
-      carry += tile_tot;
     }
-    if (tid == 0) counts[L] = m;
-    __threadfence_block();
-    __syncthreads();
-    uint64_t* t = cur; cur = nxt; nxt = t;
-    n_cur = (int)m;
-    end = base_out;
   }
+#pragma unroll
+  for (int w = 0; w < 5; ++w) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) f[w] += __shfl_xor(f[w], d, 64);
+  }
+  if (lane < OCT_MAXD + 2) {
+    unsigned long long word = f[0];
+#pragma unroll
+    for (int w = 1; w < 5; ++w) word = (lane >> 2) == w ? f[w] : word;
+    s_wcnt[wave][lane] = (uint32_t)(word >> (16 * (lane & 3))) & 0xFFFFu;
+  }
+  __syncthreads();
+  if (tid < depth) {  // thread L: level-L nodes opened by each wave, exclusive prefix over the waves
+    uint32_t run = 0;
+    for (int w = 0; w < OCT_W; ++w) {
+      uint32_t c = 0;
+      for (int v = 0; v <= tid; ++v) c += s_wcnt[w][v];
+      s_run[w][tid] = run;
+      run += c;
+    }
+    counts[tid] = run;
+    s_off[tid] = run;  // node count for now, offsets below
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t off = 0;
+    for (int L = 0; L < depth; ++L) {
+      const uint32_t c = s_off[L];
+      s_off[L] = off;
+      off += c;
+    }
+    s_off[depth] = off;  // total bytes
+    counts[depth] = (uint32_t)n;
+  }
+  __syncthreads();
+  const uint32_t tot = s_off[depth];
+  if (tot > (uint32_t)cap) return;  // the host sees the counts and reports the capacity error
+  const uint32_t words = (tot + 3u) / 4u;
+  const bool in_lds = words <= OCT_LDS_WORDS;  // block-uniform
+  if (in_lds) {
+    for (uint32_t j = tid; j < words; j += OCT_T) s_occ[j] = 0u;
+  } else {
+    for (uint32_t j = tid; j < words; j += OCT_T) occ32[j] = 0u;
+    __threadfence();
+  }
+  __syncthreads();
+
+  // sweep 2: rank the chunk's leaves per level with ballots and OR the octants into the parents' bytes.  The
+  // running node count of level L lives in lane L's register (read with v_readlane, no LDS round trip per level)
+  uint32_t run_reg = lane < depth ? s_run[wave][lane] : 0u;
+  tail = k_before;
+  for (int e0 = c0; e0 < c1; e0 += 64 * OCT_U) {
+    uint64_t kc[OCT_U];
+#pragma unroll
+    for (int u = 0; u < OCT_U; ++u) kc[u] = (keys[min(e0 + u * 64 + lane, n - 1)] >> shift) & mask;
+#pragma unroll
+    for (int u = 0; u < OCT_U; ++u) {
+      if (e0 + u * 64 >= c1) break;  // wave-uniform
+      const int e = e0 + u * 64 + lane;
+      const bool valid = e < c1;
+      const uint64_t up = __shfl_up((unsigned long long)kc[u], 1, 64);
+      const uint64_t kp = lane == 0 ? tail : up;
+      tail = __shfl((unsigned long long)kc[u], 63, 64);
+      const int lm = valid ? oct_lmin(kp, kc[u], e == 0, depth) : OCT_MAXD + 2;
+      // 64 consecutive Morton-sorted leaves share their upper levels: below the wave's smallest lmin - 1 no lane
+      // opens a node or a child, so those levels are skipped (typically 3-4 of 13 remain)
+      int lo = lm;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) lo = min(lo, __shfl_xor(lo, d, 64));
+      for (int L = max(lo - 1, 0); L < depth; ++L) {
+        const uint64_t m = __ballot(lm <= L);
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)run_reg, L);
+        if (valid && lm <= L + 1) {  // opens a node at level L+1: its octant goes into its level-L node
+          const uint32_t at = s_off[L] + before + (uint32_t)__popcll(m & lanes_le) - 1u;
+          const uint32_t oct = (uint32_t)(kc[u] >> (3 * (depth - L - 1))) & 7u;
+          const uint32_t bits = (1u << oct) << (8u * (at & 3u));
+          if (in_lds) atomicOr(&s_occ[at >> 2], bits);
+          else atomicOr(&occ32[at >> 2], bits);
+        }
+        if (lane == L) run_reg += (uint32_t)__popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+  if (in_lds)
+    for (uint32_t j = tid; j < words; j += OCT_T) occ32[j] = s_occ[j];
 }
 
 extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift,
@@ -156,10 +225,10 @@ extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n
   const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
 
   if (n <= OCT_SMALL_MAX) {
-    // one launch; levels packed back to front in occ_lv[0 .. depth*n1), one read-back, one copy
+    // one launch; levels packed root-first from occ_lv[0], one read-back, one copy
     const int cap_s = (int)((size_t)depth * n1);
     hipLaunchKernelGGL(k_oct_small, dim3(1), dim3(OCT_T), 0, st, d_keys, (int)n, key_shift, leaf_mask, depth,
-                       buf_a, buf_b, occ_lv, cap_s, counts);
+                       (uint32_t*)occ_lv, cap_s, counts);
     PCC_CHECK_LAUNCH();
     uint32_t* hc = (uint32_t*)ctx->pinned;
     PCC_HIP(hipMemcpyAsync(hc, counts, (size_t)(depth + 1) * 4, hipMemcpyDeviceToHost, st));
@@ -174,7 +243,8 @@ extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n
                 (long long)h_level_n[0]);
     PCC_REQUIRE(tot <= cap, PCC_E_ARG, "pcc_octree_levels: d_occ capacity %lld < %lld", (long long)cap,
                 (long long)tot);
-    PCC_HIP(hipMemcpyAsync(d_occ, occ_lv + (cap_s - tot), (size_t)tot, hipMemcpyDeviceToDevice, st));
+    PCC_REQUIRE(tot <= cap_s, PCC_E_ARG, "pcc_octree_levels: %lld nodes for %lld leaves", (long long)tot, (long long)n);
+    PCC_HIP(hipMemcpyAsync(d_occ, occ_lv, (size_t)tot, hipMemcpyDeviceToDevice, st));
     return PCC_OK;
   }
 

@@ -4,6 +4,13 @@
 // radix-sort digit offsets, octree level build).  Three launches per level of
 // recursion; the tile is 2048 elements (256 threads x 8, two dwordx4 loads per
 // lane), wave64 shuffles for the in-wave part, one LDS exchange per block.
+//
+// Tried and dropped: one launch per scan with the tiles chained by decoupled
+// look-back (ticketed tile order, epoch-tagged status words).  With every tile of
+// these sizes resident at once nobody but tile 0 holds an inclusive prefix, so a
+// tile sums aggregates 64 at a time all the way back — tile_count / 64 dependent
+// cross-XCD round trips: 0.5 ms slower per 1M-point step for all scans, no faster
+// than the three short launches even when limited to <= 256 tiles.
 #include "common.h"
 
 #define SCAN_THREADS 256
@@ -131,4 +138,17 @@ int pcc_scan_exclusive_u32(pcc_ctx* ctx, const uint32_t* d_in, uint32_t* d_out,
                      ctx->stream, d_in, d_out, n, (const uint32_t*)sums, d_total);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
+}
+
+// Building block exported for the op-level tests (every compaction of the path goes through it).
+extern "C" int pcc_exclusive_scan_u32(pcc_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n,
+                                      uint32_t* d_total) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_exclusive_scan_u32: null ctx");
+  PCC_REQUIRE(n <= 0 || (d_in && d_out), PCC_E_ARG, "pcc_exclusive_scan_u32: null buffer");
+  PCC_REQUIRE((uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0, PCC_E_ARG,
+              "pcc_exclusive_scan_u32: buffers must be 16-byte aligned");
+  pcc_arena_reset(ctx);
+  PCC_TRY(pcc_arena_reserve(ctx, pcc_scan_scratch_bytes(n)));
+  PccProfScope prof(ctx, "scan", n, 0, 0, 0);
+  return pcc_scan_exclusive_u32(ctx, d_in, d_out, n, d_total);
 }

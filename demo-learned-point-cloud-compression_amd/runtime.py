@@ -149,6 +149,14 @@ class Runtime:
             out.append((name.value.decode(), float(ms.value), tuple(int(d) for d in dims)))
         return out
 
+    def exclusive_scan(self, t, inplace=False):
+        """exclusive prefix sum of an int32 / uint32 vector (mod 2^32): returns (scan, total tensor [1])"""
+        n = t.shape[0]
+        out = t if inplace else self.empty((n,), torch.int32)
+        total = self.empty((1,), torch.int32)
+        check(self.lib.pcc_exclusive_scan_u32(self.ctx, _ptr(t), _ptr(out), n, _ptr(total)), "pcc_exclusive_scan_u32")
+        return out, total
+
     def count_nonneg(self, t):
         cnt = C.c_int64(0)
         check(self.lib.pcc_count_nonneg(self.ctx, _ptr(t), t.numel(), C.byref(cnt)), "pcc_count_nonneg")

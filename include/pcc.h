@@ -205,6 +205,15 @@ int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                          int cin, int cout, int relu, float* d_out,
                          const float* d_head_w, const float* d_head_b,
                          float* d_head_out);
+/* building block of every compaction on the path (stride-2 parent dedup, top-k
+ * pruning, radix-sort offsets, octree levels — the work torch.unique / ME's
+ * coordinate manager do inside the reference's ME.SparseTensor and pruning
+ * calls): exclusive prefix sum, d_out[i] = sum d_in[0..i), wrapping mod 2^32;
+ * d_in and d_out may alias; d_total (device, nullable) receives the grand total.
+ * Reduce-then-scan over 2048-element tiles. */
+int pcc_exclusive_scan_u32(pcc_ctx* ctx, const uint32_t* d_in, uint32_t* d_out,
+                           int64_t n, uint32_t* d_total);
+
 /* The g_s stage form of the two above with the rule book formed on the fly.
  * The conv3 of a synthesis stage runs on the 8 generative children (row 8p+o) of
  * the n_parents rows of the level below; d_nbr_parent is THAT level's 27-offset

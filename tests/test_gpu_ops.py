@@ -89,10 +89,56 @@ def test_sort_coords_is_reference_order(rt, oracle, clouds, name):
     assert all(tuple(srt[i]) < tuple(srt[i + 1]) for i in range(len(srt) - 1))
 
 
+@pytest.mark.parametrize("case", ["latent", "one", "two", "dups", "wide", "wide_dups", "out_of_range", "max_rows"])
+def test_sort_coords_routes(rt, oracle, case):
+    """the three routes of the latent-sized canonical sort: rank by presence bitmap (distinct rows, key domain
+    <= 2^20), radix passes on the compact key (repeated rows or a wider domain; the order among equal rows must be
+    the stable one), radix passes on the decimal key (coordinates outside +-50000)"""
+    rng = np.random.default_rng(11)
+    if case == "latent":      # stride-8 latent of a few frames, some negative: ~18-bit domain
+        c = random_cloud(rng, 20000, extent=48, batches=3, lo=-20, stride=8)
+    elif case == "one":
+        c = np.array([[2, -8, 16, 24]], np.int32)
+    elif case == "two":
+        c = np.array([[0, 8, 0, 0], [0, -8, 0, 0]], np.int32)
+    elif case == "dups":
+        c = random_cloud(rng, 3000, extent=20, batches=2, lo=-5, stride=8)
+        c = np.concatenate([c, c[::7], c[::13]])[rng.permutation(3000 + len(c[::7]) + len(c[::13]))]
+    elif case == "wide":      # distinct rows, domain of ~2^27 keys
+        c = random_cloud(rng, 5000, extent=512, batches=1, lo=-256, stride=1)
+    elif case == "wide_dups":
+        c = random_cloud(rng, 2000, extent=512, batches=2, lo=-256, stride=1)
+        c = np.concatenate([c, c[:500]])
+    elif case == "out_of_range":
+        c = random_cloud(rng, 2000, extent=64, batches=2, lo=-32, stride=1)
+        c[:, 1] *= 2000
+    else:                     # 65536 rows: the largest single-workgroup case, 2^16 of a 2^18-key domain
+        g = np.stack(np.meshgrid(np.arange(64), np.arange(64), np.arange(64), indexing="ij"), -1).reshape(-1, 3)
+        g = g[rng.permutation(len(g))[:65536]] * 4 - 100
+        c = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    perm = host(rt.sort_coords(dev(rt, c))).view(np.uint32)
+    assert np.array_equal(perm, oracle.canonical_perm(c).astype(np.uint32))
+
+
 def test_batch_offsets(rt, oracle, clouds):
     keys = sorted_keys(oracle, clouds["rand"])
     offs = rt.batch_offsets(dev(rt, keys.view(np.int64)), 3)
     assert offs == oracle.batch_offsets(keys, 3)
+
+
+@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 4096, 100_003, 3_262_640, 20_000_000])
+def test_exclusive_scan(rt, n):
+    """sizes from one tile to ~10k tiles (one to three levels of recursion), repeated on the same ctx, in place
+    and out of place, with values that wrap mod 2^32"""
+    rng = np.random.default_rng(n)
+    for rep in range(3):
+        hi = 3 if rep < 2 else 1 << 31
+        a = rng.integers(0, hi, n, dtype=np.uint32)
+        ref = np.concatenate([np.zeros(1, np.uint64), np.cumsum(a.astype(np.uint64))]) & np.uint64(0xFFFFFFFF)
+        d = dev(rt, a.view(np.int32))
+        out, tot = rt.exclusive_scan(d, inplace=(rep == 1))
+        assert np.array_equal(host(out).view(np.uint32), ref[:-1].astype(np.uint32))
+        assert host(tot).view(np.uint32)[0] == np.uint32(ref[-1])
 
 
 # ---------------------------------------------------------------- coordinate maps
@@ -477,6 +523,26 @@ def test_octree_blob_matches_oracle_and_round_trips(rt, oracle, clouds, name):
     pts = utils.gpcc_decode(blob, 8)
     assert np.array_equal(pts, oracle.keys_to_coords(keys)[:, 1:])
     assert np.array_equal(oracle.octree_decode(blob) * 8, pts)
+
+
+@pytest.mark.parametrize("n,extent", [(60000, 6000), (65536, 48), (65537, 48), (2, 3), (9, 2)])
+def test_octree_single_launch_sizes(rt, oracle, n, extent):
+    """the one-workgroup octree kernel: scattered leaves whose occupancy bytes exceed its LDS buffer (60000 leaves
+    over +-3000: the bytes are ORed into HBM instead), the largest single-launch input and the first size that
+    takes the per-level kernels, and the smallest trees"""
+    runtime, utils = pkg("runtime"), pkg("utils")
+    rng = np.random.default_rng(n)
+    if extent ** 3 < 4 * n:
+        g = np.stack(np.meshgrid(*[np.arange(extent)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        g = g[rng.permutation(len(g))[:n]] - extent // 2
+    else:
+        g = np.unique(rng.integers(-extent // 2, extent // 2, (2 * n, 3)), axis=0)
+        g = g[rng.permutation(len(g))[:n]]
+    c = np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+    keys = sorted_keys(oracle, c)
+    blob = utils.gpcc_encode(dev(rt, keys.view(np.int64)), keys.view(np.int64), 0, len(keys), 0)
+    assert blob == oracle.octree_encode(c[:, 1:], 32768)
+    assert np.array_equal(utils.gpcc_decode(blob, 1), oracle.keys_to_coords(keys)[:, 1:])
 
 
 def test_octree_stride1_large_extent(rt, oracle):
