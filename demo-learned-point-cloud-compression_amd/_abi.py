@@ -41,6 +41,8 @@ PROTOTYPES = {
     "pcc_codec_ctx": (vp, [vp]),
     "pcc_encode_gop": (i32, [vp, vp, vp, i64, i32, C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64,
                              C.POINTER(C.c_double)]),
+    "pcc_encode_gop_frames": (i32, [vp, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p), i32, pi64, i32,
+                                    C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64, C.POINTER(C.c_double)]),
     "pcc_decode_gop": (i32, [vp, vp, i64, C.POINTER(PccCloudInfo), C.POINTER(C.c_double)]),
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
     "pcc_sparse_conv_head_up": (i32, [vp, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp, vp]),

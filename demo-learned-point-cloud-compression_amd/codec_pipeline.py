@@ -43,6 +43,16 @@ def _to_dev(a, dtype, device):
     return t.contiguous()
 
 
+def _to_dev_as_is(a, keep, other, device):
+    """upload without a cast when the dtype is one the library reads directly (`keep`), else cast to `other`"""
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype not in keep:
+        t = t.to(other)
+    if t.device != device:
+        t = t.to(device, non_blocking=True)
+    return t.contiguous()
+
+
 class CompressionPipeline:
     def __init__(self, settings, device=0, slots=3, stage_sync=None, engine=None):
         self.device = torch.device("cuda", device)
@@ -155,12 +165,21 @@ class CompressionPipeline:
         codec = self._slots.get()
         try:
             with torch.cuda.stream(codec.stream):
-                pts = [_to_dev(it["points"], torch.int32, self.device) for it in items]
-                cols = [_to_dev(it["colors"], torch.float32, self.device) for it in items]
-                coords, colors = utils.stack_tensors(pts, cols)
-                feats = torch.cat([torch.ones((colors.shape[0], 1), device=colors.device), colors], dim=1)
-                out, k, times = codec.encode(coords.contiguous(), feats.contiguous(), len(items), self.settings)
-                num_points = int(coords.shape[0])
+                pts = [_to_dev_as_is(it["points"], (torch.int16, torch.int32), torch.int32, self.device)
+                       for it in items]
+                cols = [_to_dev_as_is(it["colors"], (torch.float32, torch.float64), torch.float32, self.device)
+                        for it in items]
+                num_points = sum(int(p.shape[0]) for p in pts)
+                same = len({p.dtype for p in pts}) == 1 and len({c.dtype for c in cols}) == 1
+                if same and len(items) <= codec.MAX_FRAMES:
+                    # frames go in as they are: batch column, casts and (1,r,g,b) rows are formed in the kernels
+                    out, k, times = codec.encode_frames(pts, cols, self.settings)
+                else:
+                    pts = [p.to(torch.int32) for p in pts]
+                    cols = [c.to(torch.float32) for c in cols]
+                    coords, colors = utils.stack_tensors(pts, cols)
+                    feats = torch.cat([torch.ones((colors.shape[0], 1), device=colors.device), colors], dim=1)
+                    out, k, times = codec.encode(coords.contiguous(), feats.contiguous(), len(items), self.settings)
         finally:
             self._slots.put(codec)
         for i, b in enumerate(out):

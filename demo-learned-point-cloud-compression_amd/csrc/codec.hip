@@ -604,10 +604,68 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
 extern "C" pcc_ctx* pcc_codec_ctx(pcc_codec* cd) { return cd ? cd->ctx : nullptr; }
 
 // ---------------------------------------------------------------------------- encode
+// The frames of a GOP as the capture stage hands them over (capturer.py:111-126 — per frame points [n_f,3] int16 or
+// int32 and colours [n_f,3] float64 or float32, here already in HBM): unpack_batch's concatenation, batch column,
+// dtype casts and the (1,r,g,b) feature rows (codec_pipeline.py:243-262, shared/utils.py:10-42) happen inside the
+// two kernels that need the values — the Morton keys are formed straight from the frame arrays and the sorted
+// feature rows are gathered straight from the colour arrays; no [N,4] staging tensors.
+#define PCC_MAX_FRAMES_ARG 32
+struct FrameTab {
+  const void* pts[PCC_MAX_FRAMES_ARG];
+  const void* cols[PCC_MAX_FRAMES_ARG];
+  long long off[PCC_MAX_FRAMES_ARG + 1];  // row offsets of the frames in the concatenation
+  int nf, pts_i16, cols_f64;
+};
+
+__device__ __forceinline__ int frame_of(const FrameTab& t, long long i) {
+  int f = 0;
+  while (f + 1 < t.nf && i >= t.off[f + 1]) ++f;
+  return f;
+}
+
+__global__ __launch_bounds__(256) void k_frames_keys(FrameTab t, int64_t n, uint64_t* __restrict__ keys,
+                                                     int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = frame_of(t, i);
+  const int64_t j = i - t.off[f];
+  int x, y, z;
+  if (t.pts_i16) {
+    const int16_t* p = (const int16_t*)t.pts[f] + 3 * j;
+    x = p[0]; y = p[1]; z = p[2];
+  } else {
+    const int32_t* p = (const int32_t*)t.pts[f] + 3 * j;
+    x = p[0]; y = p[1]; z = p[2];
+    const bool bad = (x < -32768) | (x > 32767) | (y < -32768) | (y > 32767) | (z < -32768) | (z > 32767);
+    if (bad) atomicOr(flag, 1);
+  }
+  keys[i] = pcc_morton(f, x, y, z);
+}
+
+// feature row i of the Morton-sorted tensor = (1, r, g, b) of concatenated row perm[i]
+__global__ __launch_bounds__(256) void k_frames_feats(FrameTab t, const uint32_t* __restrict__ perm, int64_t n,
+                                                      float4* __restrict__ feats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long src = perm[i];
+  const int f = frame_of(t, src);
+  const int64_t j = src - t.off[f];
+  float r, g, b;
+  if (t.cols_f64) {
+    const double* c = (const double*)t.cols[f] + 3 * j;
+    r = (float)c[0]; g = (float)c[1]; b = (float)c[2];
+  } else {
+    const float* c = (const float*)t.cols[f] + 3 * j;
+    r = c[0]; g = c[1]; b = c[2];
+  }
+  feats[i] = make_float4(1.0f, r, g, b);
+}
+
 static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n, int n_frames,
-                           const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s) {
+                           const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s,
+                           const FrameTab* frames = nullptr) {
   PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_encode_gop: null codec");
-  PCC_REQUIRE(n > 0 && d_coords && d_feats && n_frames >= 1 && n_frames <= 65535 && h_q && n_q >= 1 &&
+  PCC_REQUIRE(n > 0 && (frames || (d_coords && d_feats)) && n_frames >= 1 && n_frames <= 65535 && h_q && n_q >= 1 &&
                   n_q <= 64 && h_out,
               PCC_E_ARG, "pcc_encode_gop: bad argument (n=%lld frames=%d q=%d)", (long long)n, n_frames, n_q);
   pcc_ctx* ctx = cd->ctx;
@@ -629,7 +687,12 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     CODEC_ALLOC(perm, uint32_t, n);
     CODEC_ALLOC(f, float, 4 * n);
     PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
-    PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
+    if (frames) {
+      hipLaunchKernelGGL(k_frames_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *frames, n, keys, flag);
+      PCC_CHECK_LAUNCH();
+    } else {
+      PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
+    }
     PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
     PCC_TRY(cd->pin_flag.ensure(64));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
@@ -639,7 +702,13 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE,
                 "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0,65534]");
     PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_encode_gop: duplicate coordinates");
-    PCC_TRY(pcc_gather_rows(ctx, d_feats, perm, n, 16, f));
+    if (frames) {
+      hipLaunchKernelGGL(k_frames_feats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *frames,
+                         (const uint32_t*)perm, n, (float4*)f);
+      PCC_CHECK_LAUNCH();
+    } else {
+      PCC_TRY(pcc_gather_rows(ctx, d_feats, perm, n, 16, f));
+    }
     x = {new_set(cd, keys, n, 1, n_frames), f, 4};
   }
 
@@ -1243,6 +1312,38 @@ extern "C" int pcc_encode_gop(pcc_codec* cd, const int32_t* d_coords, const floa
     return PCC_E_NOMEM;
   } catch (const std::exception& e) {
     pcc_set_error("pcc_encode_gop: %s", e.what());
+    return PCC_E_ARG;
+  }
+}
+
+extern "C" int pcc_encode_gop_frames(pcc_codec* cd, const void* const* h_d_points, int points_i16,
+                                     const void* const* h_d_colors, int colors_f64, const int64_t* h_n, int n_frames,
+                                     const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s) {
+  PCC_REQUIRE(h_d_points && h_d_colors && h_n && n_frames >= 1, PCC_E_ARG, "pcc_encode_gop_frames: null frame table");
+  PCC_REQUIRE(n_frames <= PCC_MAX_FRAMES_ARG, PCC_E_ARG,
+              "pcc_encode_gop_frames: %d frames, at most %d per call (concatenate and use pcc_encode_gop)", n_frames,
+              PCC_MAX_FRAMES_ARG);
+  FrameTab t;
+  memset(&t, 0, sizeof(t));
+  t.nf = n_frames;
+  t.pts_i16 = points_i16 ? 1 : 0;
+  t.cols_f64 = colors_f64 ? 1 : 0;
+  for (int f = 0; f < n_frames; ++f) {
+    PCC_REQUIRE(h_n[f] >= 0 && (h_n[f] == 0 || (h_d_points[f] && h_d_colors[f])), PCC_E_ARG,
+                "pcc_encode_gop_frames: frame %d: n=%lld or null arrays", f, (long long)h_n[f]);
+    t.pts[f] = h_d_points[f];
+    t.cols[f] = h_d_colors[f];
+    t.off[f + 1] = t.off[f] + h_n[f];
+  }
+  const int64_t n = t.off[n_frames];
+  PCC_REQUIRE(n < ((int64_t)1 << 32), PCC_E_ARG, "pcc_encode_gop_frames: %lld points", (long long)n);
+  try {
+    return encode_gop_impl(cd, nullptr, nullptr, n, n_frames, h_q, n_q, h_out, h_k, h_stage_s, &t);
+  } catch (const std::bad_alloc&) {
+    pcc_set_error("pcc_encode_gop_frames: out of host memory");
+    return PCC_E_NOMEM;
+  } catch (const std::exception& e) {
+    pcc_set_error("pcc_encode_gop_frames: %s", e.what());
     return PCC_E_ARG;
   }
 }

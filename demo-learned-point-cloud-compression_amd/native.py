@@ -99,6 +99,34 @@ class NativeCodec:
         ks = [[int(k[s * n_frames + f]) for f in range(n_frames)] for s in range(3)]
         return out, ks, dict(zip(ENC_STAGES, ts))
 
+    MAX_FRAMES = 32  # PCC_MAX_FRAMES_ARG of codec.hip
+
+    def encode_frames(self, points, colors, settings):
+        """the same on per-frame device tensors as the capture stage leaves them: points [n_f,3] int16 or int32,
+        colors [n_f,3] float64 or float32 (one dtype per list).  Batch column, casts and the (1,r,g,b) rows are
+        formed inside the library's kernels (pcc_encode_gop_frames); at most MAX_FRAMES frames."""
+        nf, nq = len(points), len(settings)
+        assert 1 <= nf <= self.MAX_FRAMES and len(colors) == nf
+        pdt, cdt = points[0].dtype, colors[0].dtype
+        assert pdt in (torch.int16, torch.int32) and cdt in (torch.float32, torch.float64)
+        for p, c in zip(points, colors):
+            assert p.is_cuda and c.is_cuda and p.dtype == pdt and c.dtype == cdt and p.is_contiguous()
+            assert c.is_contiguous() and p.shape == c.shape and p.ndim == 2 and p.shape[1] == 3
+        pp = (C.c_void_p * nf)(*[p.data_ptr() for p in points])
+        cp = (C.c_void_p * nf)(*[c.data_ptr() for c in colors])
+        ns = (C.c_int64 * nf)(*[int(p.shape[0]) for p in points])
+        q = (C.c_double * (2 * nq))(*[float(v) for s in settings for v in s[:2]])
+        bufs = (_abi.PccBuf * nq)()
+        k = (C.c_int64 * (3 * nf))()
+        ts = (C.c_double * 7)()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        check(self.lib.pcc_encode_gop_frames(self.handle, pp, 1 if pdt == torch.int16 else 0, cp,
+                                             1 if cdt == torch.float64 else 0, ns, nf, q, nq, bufs, k, ts),
+              "pcc_encode_gop_frames")
+        out = [C.string_at(bufs[i].data, bufs[i].len) for i in range(nq)]
+        ks = [[int(k[s * nf + f]) for f in range(nf)] for s in range(3)]
+        return out, ks, dict(zip(ENC_STAGES, ts))
+
     # ------------------------------------------------------------------ decode
     def decode(self, data):
         """container bytes -> (coords int32 [n,4] device, colors float32 [n,3] device, offsets, q, stage seconds).

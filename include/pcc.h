@@ -433,6 +433,20 @@ int pcc_encode_gop(pcc_codec* codec, const int32_t* d_coords,
                    const float* d_feats, int64_t n, int n_frames,
                    const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k,
                    double* h_stage_s);
+/* The same call on the frames as the capture stage produces them
+ * (sender/capturer/capturer.py:111-126; consumed by unpack_batch,
+ * codec_pipeline.py:243-262, and utils.stack_tensors, shared/utils.py:10-42):
+ * per frame f, h_d_points[f] = device array [h_n[f],3] of int16 (points_i16 != 0)
+ * or int32 voxel coordinates, h_d_colors[f] = device array [h_n[f],3] of float64
+ * (colors_f64 != 0) or float32 colours in [0,1].  The batch column, the casts and
+ * the (1,r,g,b) rows are formed inside the key and gather kernels; at most 32
+ * frames per call (more: concatenate and use pcc_encode_gop).  The h_* tables are
+ * host arrays of n_frames entries.  Same outputs and errors as pcc_encode_gop. */
+int pcc_encode_gop_frames(pcc_codec* codec, const void* const* h_d_points,
+                          int points_i16, const void* const* h_d_colors,
+                          int colors_f64, const int64_t* h_n, int n_frames,
+                          const double* h_q, int n_q, pcc_buf* h_out,
+                          int64_t* h_k, double* h_stage_s);
 /* h_stage_s (nullable) double[6] seconds = bitstream_reading,
  * geometry_decompression, factorized_model, hyper_synthesis, guassian_model,
  * synthesis_transform.  Truncated / inconsistent containers: PCC_E_STREAM. */

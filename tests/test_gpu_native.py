@@ -51,6 +51,11 @@ def test_native_gop_equals_python_ops_and_oracle(wl, oracle, codec, name):
     for q in range(len(SETTINGS)):
         assert cont[q] == out[q + 1], f"container {q + 1} differs from the op-by-op path"
     assert set(times) == set(side["enc_time_measurements"])
+    # the per-frame entry point (frames as the capturer leaves them: int16 points, float64 colours)
+    cont_f, ks_f, _ = codec.encode_frames([torch.from_numpy(np.ascontiguousarray(f["points"])).cuda() for f in frames],
+                                          [torch.from_numpy(np.ascontiguousarray(f["colors"])).cuda() for f in frames],
+                                          SETTINGS)
+    assert cont_f == cont and ks_f == ks
     ref, _ = oracle.compress(frames, SETTINGS)
     for q in range(len(SETTINGS)):
         assert cont[q] == ref[q + 1], f"container {q + 1} differs from the oracle"
@@ -68,6 +73,45 @@ def test_native_gop_equals_python_ops_and_oracle(wl, oracle, codec, name):
             item = np.clip(np.nan_to_num(colh[offs[i]:offs[i + 1]], nan=0.0) * 255.0, 0, 255) / 255
             assert np.array_equal(item, fr["colors"])
             assert np.array_equal(fr["points"], oref[i]["points"]) and np.array_equal(fr["colors"], oref[i]["colors"])
+
+
+def test_native_frame_tables(wl, codec):
+    """pcc_encode_gop_frames: every dtype pair it reads directly, an empty frame in the middle, 32 frames (its
+    limit) and the errors; the pipeline class falls back to its own stacking for mixed dtypes and longer GOPs"""
+    frames = [wl.sphere_shell(24, 9.1, seed=s, offset=(3 * s, -2 * s, s)) for s in range(1, 4)]
+    coords, feats = _stack(frames)
+    ref, ks, _ = codec.encode(coords, feats, len(frames), SETTINGS)
+    for pdt in (torch.int16, torch.int32):
+        for cdt in (torch.float64, torch.float32):
+            # float32 colours: the reference casts float64 -> float32 first, so feed the already-cast values
+            pts = [torch.from_numpy(f["points"].astype(np.int64)).to(pdt).cuda() for f in frames]
+            cols = [torch.from_numpy(f["colors"].astype(np.float32 if cdt == torch.float32 else np.float64)).cuda()
+                    for f in frames]
+            got, ks2, _ = codec.encode_frames(pts, cols, SETTINGS)
+            assert got == ref and ks2 == ks
+    native = pkg("native")
+    rtm = pkg("runtime")
+    # out-of-range int32 coordinate -> PCC_E_RANGE, duplicates -> PCC_E_DUP
+    bad = [torch.tensor([[0, 0, 0], [40000, 0, 0]], dtype=torch.int32).cuda()]
+    with pytest.raises(rtm.PccError) as e:
+        codec.encode_frames(bad, [torch.zeros((2, 3)).cuda()], SETTINGS)
+    assert e.value.code == -3
+    dup = [torch.tensor([[1, 2, 3], [1, 2, 3]], dtype=torch.int16).cuda()]
+    with pytest.raises(rtm.PccError) as e:
+        codec.encode_frames(dup, [torch.zeros((2, 3)).cuda()], SETTINGS)
+    assert e.value.code == -4
+    # pipeline class: an empty frame inside the GOP, 32 and 33 frames, mixed dtypes — all equal to the op-by-op path
+    cp = pkg("codec_pipeline")
+    enc_n = cp.CompressionPipeline(SETTINGS, slots=1)
+    enc_o = cp.CompressionPipeline(SETTINGS, slots=1, engine="ops")
+    small = [wl.sphere_shell(12, 4.0, seed=s, offset=(s, s, -s)) for s in range(33)]
+    empty = {"points": np.zeros((0, 3), np.int16), "colors": np.zeros((0, 3), np.float64)}
+    mixed = [dict(frames[0]), {"points": frames[1]["points"].astype(np.int32),
+                               "colors": frames[1]["colors"].astype(np.float32)}]
+    for gop in ([frames[0], empty, frames[1]], small[:32], small, mixed):
+        a, _ = enc_n.compress(wl.gop([dict(f) for f in gop]))
+        b, _ = enc_o.compress(wl.gop([dict(f) for f in gop]))
+        assert [a[q] for q in (1, 2, 3)] == [b[q] for q in (1, 2, 3)]
 
 
 def test_native_errors(codec):
