@@ -333,6 +333,10 @@ def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
     refr = np.maximum(ref, 0)
     assert np.array_equal(host(feats), refr)
     assert np.array_equal(host(logits), oracle.linear(refr, hw, hb)[:, 0])
+    # the 32 -> 64 layer (dense-tile kernel) on the same neighbourhoods
+    w64, b64 = _weights(rng, 27, 32, 64)
+    out64 = rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w64), dev(rt, b64), True)
+    assert np.array_equal(host(out64), oracle.sparse_conv(x, nbr, w64, b64, True))
 
 
 @pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
