@@ -149,6 +149,7 @@ struct CS {
   int32_t* parent_of = nullptr;
   CS* up = nullptr;          // generative children at stride/2, once made
   CS* gen_parent = nullptr;  // set whose generative children these rows are (row 8p+o)
+  std::vector<int64_t> down_counts;  // row counts of the successive parent levels, when known (pcc_level_counts)
   CS* subset_of = nullptr;   // candidate set this set was pruned from, with the kept rows
   uint32_t* keep = nullptr;
 };
@@ -229,9 +230,14 @@ int down_of(pcc_codec* cd, CS* s) {
   CODEC_ALLOC(nbr8, int32_t, 8 * cap);
   CODEC_ALLOC(parent_of, int32_t, cap);
   int64_t m = 0;
-  if (s->n > 0)
+  if (s->n > 0 && !s->down_counts.empty()) {  // size known: no read-back, the stream keeps running
+    m = s->down_counts[0];
+    PCC_TRY(pcc_down_coords_known(cd->ctx, s->keys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, m));
+  } else if (s->n > 0) {
     PCC_TRY(pcc_down_coords(cd->ctx, s->keys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, &m));
+  }
   s->down = new_set(cd, pkeys, m, s->stride * 2, s->n_batch);
+  if (s->down_counts.size() > 1) s->down->down_counts.assign(s->down_counts.begin() + 1, s->down_counts.end());
   s->nbr8 = nbr8;
   s->parent_of = parent_of;
   return PCC_OK;
@@ -696,8 +702,11 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
     PCC_TRY(cd->pin_flag.ensure(64));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
+    // one read-back for the duplicate check and the sizes of the five pyramid levels above the input (g_a: strides
+    // 2, 4, 8; h_a: 16, 32), instead of one per level
     int dup = 0;
-    PCC_TRY(pcc_check_unique(ctx, keys, n, &dup));
+    std::vector<int64_t> level_n(5, 0);
+    PCC_TRY(pcc_level_counts(ctx, keys, n, 0, 5, level_n.data(), &dup));
     PCC_HIP(hipStreamSynchronize(st));
     PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE,
                 "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0,65534]");
@@ -710,6 +719,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_TRY(pcc_gather_rows(ctx, d_feats, perm, n, 16, f));
     }
     x = {new_set(cd, keys, n, 1, n_frames), f, 4};
+    x.cs->down_counts = level_n;
   }
 
   // ---- step 1: analysis g_a + canonical order of y (codec_pipeline.py:270-281)
@@ -1116,6 +1126,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   t0 = now_s();
   CS* ycs;
   {
+    std::vector<int64_t> y_level_n(2, 0);
     CODEC_ALLOC(yc, int32_t, 4 * std::max<int64_t>(ny, 1));
     CODEC_ALLOC(keys, uint64_t, std::max<int64_t>(ny, 1));
     CODEC_ALLOC(flag, int32_t, 1);
@@ -1128,12 +1139,13 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
       PCC_TRY(cd->pin_flag.ensure(64));
       PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
       int dup = 0;
-      PCC_TRY(pcc_check_unique(ctx, keys, ny, &dup));
+      PCC_TRY(pcc_level_counts(ctx, keys, ny, 9, 2, y_level_n.data(), &dup));  // + sizes of the stride-16 / 32 sets
       PCC_HIP(hipStreamSynchronize(st));
       PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE, "pcc_decode_gop: decoded coordinate out of range");
       PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_decode_gop: duplicate latent coordinates");
     }
     ycs = new_set(cd, keys, ny, 8, std::max(n_batch, 1));
+    if (ny > 0) ycs->down_counts = y_level_n;
   }
   PCC_TRY(down_of(cd, ycs));
   PCC_TRY(down_of(cd, ycs->down));

@@ -47,9 +47,76 @@ __global__ void k_up_keys(const uint64_t* __restrict__ keys, int64_t n, int cshi
   ckeys[t] = keys[t >> 3] | ((uint64_t)(t & 7) << cshift);
 }
 
+// Sizes of the whole pyramid above a sorted key set in one pass: with h = the highest bit in which key e differs
+// from key e-1, the two keys have different parents at shift s iff h >= s, so the number of distinct (key >> s) is
+// 1 + #{e >= 1 : h_e >= s}.  Histogram of h (64 bins) + a bin for equal neighbours (duplicate rows).
+__global__ __launch_bounds__(256) void k_diff_bit_hist(const uint64_t* __restrict__ keys, int64_t n,
+                                                       uint32_t* __restrict__ hist /*[65]*/) {
+  __shared__ uint32_t s_h[65];
+  if (threadIdx.x < 65) s_h[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t x = keys[e - 1] ^ keys[e];
+    atomicAdd(&s_h[x ? 63 - __builtin_clzll(x) : 64], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 65 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+extern "C" int pcc_level_counts(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift, int levels,
+                                int64_t* h_counts, int* h_dup) {
+  PCC_REQUIRE(ctx && h_counts && levels >= 1 && levels <= 16, PCC_E_ARG, "pcc_level_counts: bad argument");
+  PCC_REQUIRE(child_shift >= 0 && child_shift % 3 == 0 && child_shift + 3 * levels <= 48, PCC_E_ARG,
+              "pcc_level_counts: child_shift=%d levels=%d", child_shift, levels);
+  for (int l = 0; l < levels; ++l) h_counts[l] = 0;
+  if (h_dup) *h_dup = 0;
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_keys && n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_level_counts: bad keys");
+  hipStream_t st = ctx->stream;
+  PCC_TRY(pcc_arena_reserve(ctx, 1024));
+  uint32_t* hist = (uint32_t*)pcc_arena_alloc(ctx, 65 * 4);
+  if (!hist) return PCC_E_NOMEM;
+  PccProfScope prof(ctx, "level_counts", n, child_shift, levels, 0);
+  PCC_HIP(hipMemsetAsync(hist, 0, 65 * 4, st));
+  unsigned g = nblk(n, 256 * 8);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_diff_bit_hist, dim3(g), dim3(256), 0, st, d_keys, n, hist);
+  PCC_CHECK_LAUNCH();
+  uint32_t* h = (uint32_t*)ctx->pinned;
+  PCC_HIP(hipMemcpyAsync(h, hist, 65 * 4, hipMemcpyDeviceToHost, st));
+  PCC_HIP(hipStreamSynchronize(st));
+  for (int l = 0; l < levels; ++l) {
+    const int s = child_shift + 3 * (l + 1);
+    int64_t c = 1;
+    for (int b = s; b < 64; ++b) c += h[b];
+    h_counts[l] = c;
+  }
+  if (h_dup) *h_dup = h[64] != 0;
+  return PCC_OK;
+}
+
+static int down_coords_impl(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift, uint64_t* d_pkeys,
+                            int32_t* d_nbr8, int64_t n_cap, int32_t* d_parent_of, int64_t m_known,
+                            int64_t* h_n_out);
+
 extern "C" int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift,
                                uint64_t* d_pkeys, int32_t* d_nbr8, int64_t n_cap,
                                int32_t* d_parent_of, int64_t* h_n_out) {
+  return down_coords_impl(ctx, d_keys, n, child_shift, d_pkeys, d_nbr8, n_cap, d_parent_of, -1, h_n_out);
+}
+
+extern "C" int pcc_down_coords_known(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift,
+                                     uint64_t* d_pkeys, int32_t* d_nbr8, int64_t n_cap, int32_t* d_parent_of,
+                                     int64_t m) {
+  PCC_REQUIRE(m >= (n > 0 ? 1 : 0) && m <= n, PCC_E_ARG, "pcc_down_coords_known: m=%lld for n=%lld", (long long)m,
+              (long long)n);
+  int64_t got = 0;
+  return down_coords_impl(ctx, d_keys, n, child_shift, d_pkeys, d_nbr8, n_cap, d_parent_of, m, &got);
+}
+
+static int down_coords_impl(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift, uint64_t* d_pkeys,
+                            int32_t* d_nbr8, int64_t n_cap, int32_t* d_parent_of, int64_t m_known,
+                            int64_t* h_n_out) {
   PCC_REQUIRE(ctx && h_n_out, PCC_E_ARG, "pcc_down_coords: null arg");
   PCC_REQUIRE(child_shift >= 0 && child_shift <= 42 && child_shift % 3 == 0, PCC_E_ARG,
               "pcc_down_coords: child_shift=%d", child_shift);
@@ -68,10 +135,13 @@ extern "C" int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, 
                      child_shift + 3, flags);
   PCC_CHECK_LAUNCH();
   PCC_TRY(pcc_scan_exclusive_u32(ctx, flags, excl, n, total));
-  uint32_t* h = (uint32_t*)ctx->pinned;
-  PCC_HIP(hipMemcpyAsync(h, total, 4, hipMemcpyDeviceToHost, st));
-  PCC_HIP(hipStreamSynchronize(st));
-  const int64_t m = (int64_t)h[0];
+  int64_t m = m_known;
+  if (m < 0) {
+    uint32_t* h = (uint32_t*)ctx->pinned;
+    PCC_HIP(hipMemcpyAsync(h, total, 4, hipMemcpyDeviceToHost, st));
+    PCC_HIP(hipStreamSynchronize(st));
+    m = (int64_t)h[0];
+  }
   hipLaunchKernelGGL(k_fill_i32, dim3(nblk(8 * m, 256)), dim3(256), 0, st, d_nbr8, 8 * m, -1);
   PCC_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_emit_parents, dim3(nblk(n, 256)), dim3(256), 0, st, d_keys, n, child_shift,

@@ -220,16 +220,30 @@ class Runtime:
         return [int(v) for v in out]
 
     # ------------------------------------------------------------ pyramid / maps
-    def down_coords(self, keys, child_shift):
+    def down_coords(self, keys, child_shift, m_known=None):
+        """m_known: the parent count from level_counts — then the call does not synchronise"""
         n = keys.shape[0]
         pkeys = self.empty((n,), torch.int64)
         nbr8 = self.empty((8 * n,), torch.int32)
         parent_of = self.empty((n,), torch.int32)
-        m = C.c_int64(0)
-        check(self.lib.pcc_down_coords(self.ctx, _ptr(keys), n, child_shift, _ptr(pkeys), _ptr(nbr8), n,
-                                       _ptr(parent_of), C.byref(m)), "pcc_down_coords")
-        m = m.value
+        if m_known is None:
+            m = C.c_int64(0)
+            check(self.lib.pcc_down_coords(self.ctx, _ptr(keys), n, child_shift, _ptr(pkeys), _ptr(nbr8), n,
+                                           _ptr(parent_of), C.byref(m)), "pcc_down_coords")
+            m = m.value
+        else:
+            m = int(m_known)
+            check(self.lib.pcc_down_coords_known(self.ctx, _ptr(keys), n, child_shift, _ptr(pkeys), _ptr(nbr8), n,
+                                                 _ptr(parent_of), m), "pcc_down_coords_known")
         return pkeys[:m], nbr8[:8 * m].view(8, m), parent_of
+
+    def level_counts(self, keys, child_shift, levels):
+        """([rows of the `levels` successive parent sets of a sorted key set], duplicate-rows flag): one pass"""
+        cnt = (C.c_int64 * levels)()
+        dup = C.c_int(0)
+        check(self.lib.pcc_level_counts(self.ctx, _ptr(keys), keys.shape[0], child_shift, levels, cnt, C.byref(dup)),
+              "pcc_level_counts")
+        return [int(v) for v in cnt], bool(dup.value)
 
     def derive_map_up(self, nbr_parent, n_parents, parent_rows=None, remap=None):
         nbr = self.empty((27, 8 * n_parents), torch.int32)

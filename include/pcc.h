@@ -145,6 +145,17 @@ int pcc_down_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
                     int child_shift, uint64_t* d_pkeys, int32_t* d_nbr8,
                     int64_t n_cap, int32_t* d_parent_of /* [n], nullable */,
                     int64_t* h_n_out);
+/* The sizes of the pyramid above a sorted key set in one pass and one
+ * synchronisation: h_counts[l] = number of distinct (key >> (child_shift +
+ * 3 (l+1))), l = 0..levels-1, i.e. the *h_n_out of `levels` successive
+ * pcc_down_coords calls; *h_dup (nullable) = 1 if two neighbouring keys are equal
+ * (pcc_check_unique).  pcc_down_coords_known is pcc_down_coords with the parent
+ * count m supplied, and does not synchronise. */
+int pcc_level_counts(pcc_ctx* ctx, const uint64_t* d_sorted_keys, int64_t n,
+                     int child_shift, int levels, int64_t* h_counts, int* h_dup);
+int pcc_down_coords_known(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                          int child_shift, uint64_t* d_pkeys, int32_t* d_nbr8,
+                          int64_t n_cap, int32_t* d_parent_of, int64_t m);
 /* replaces: the generative transposed-convolution coordinate map (up stages
  * of h_s and g_s): children key = parent | o << (3*log2(ts/2)), row 8p+o. */
 int pcc_up_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,

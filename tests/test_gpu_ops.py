@@ -155,6 +155,33 @@ def test_down_coords(rt, oracle, clouds, name, stride):
     assert np.array_equal(rpk[host(parent_of)], (keys >> shift) << shift)
 
 
+@pytest.mark.parametrize("name,stride", [("rand", 1), ("surf", 1), ("tiny", 1), ("one", 1), ("surf", 8)])
+def test_level_counts_are_the_pyramid_sizes(rt, oracle, clouds, name, stride):
+    """pcc_level_counts: the sizes of five successive stride-2 parent sets (batch index included in the key) from one
+    pass, and pcc_down_coords_known fed with them == pcc_down_coords; repeated rows raise the duplicate flag"""
+    c = clouds[name].copy()
+    c[:, 1:] *= stride
+    keys = sorted_keys(oracle, c)
+    kd = dev(rt, keys.view(np.int64))
+    cshift = 3 * (stride.bit_length() - 1)
+    counts, dup = rt.level_counts(kd, cshift, 5)
+    assert not dup
+    cur, s = keys, stride
+    for lvl in range(5):
+        pk, nbr8 = oracle.down(cur, s)
+        assert counts[lvl] == len(pk)
+        if lvl < 2:
+            d = dev(rt, cur.view(np.int64))
+            a = rt.down_coords(d, 3 * (s.bit_length() - 1))
+            b = rt.down_coords(d, 3 * (s.bit_length() - 1), m_known=counts[lvl])
+            for x, y in zip(a, b):
+                assert np.array_equal(host(x), host(y))
+        cur, s = pk, s * 2
+    if len(keys) > 1:
+        twice = np.sort(np.concatenate([keys, keys[:1]]))
+        assert rt.level_counts(dev(rt, twice.view(np.int64)), cshift, 1)[1]
+
+
 @pytest.mark.parametrize("name,stride", [("surf", 1), ("rand", 2), ("tiny", 1)])
 def test_derived_map_down_equals_hash_map(rt, oracle, clouds, name, stride):
     """rule book derived from the parent level == rule book from the coordinate hash == oracle"""
