@@ -260,9 +260,9 @@ int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const float* d_w,
  * the largest logit (ties: lower row first).  d_keep_rows receives the kept
  * row indices in ascending order; *h_n_keep their number.  h_offsets as from
  * pcc_batch_offsets (n_batch+1 entries), h_k n_batch entries.  The number of
- * kept rows is sum_f min(k[f], rows of frame f) by construction: a caller that
- * computes it itself may pass h_n_keep = NULL, and the call then does not
- * synchronise the stream (GOPs of up to 8 frames). */
+ * kept rows is sum_f min(k[f], rows of frame f) by construction (no read-back);
+ * h_n_keep may be NULL.  The call does not synchronise the stream for GOPs of
+ * up to 8 frames. */
 int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, int n_batch,
                    const int64_t* h_offsets, const int64_t* h_k,
                    uint32_t* d_keep_rows, int64_t* h_n_keep);

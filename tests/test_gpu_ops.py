@@ -500,6 +500,30 @@ def test_topk_prune(rt, oracle, case):
     assert np.array_equal(host(keep).view(np.uint32), ref)
 
 
+@pytest.mark.parametrize("case", ["large", "large_ties", "twelve_frames"])
+def test_topk_prune_many_blocks(rt, oracle, case):
+    """frames of up to 2M candidates (hundreds of histogram blocks per frame: the last block of a frame to finish
+    closes the pass), ties spread over a whole frame, and a 12-frame GOP (parameters staged through pinned
+    memory instead of kernel arguments)"""
+    rng = np.random.default_rng({"large": 31, "large_ties": 32, "twelve_frames": 33}[case])
+    if case == "twelve_frames":
+        counts = [int(c) for c in rng.integers(0, 40000, 12)]
+        counts[3] = 0
+    else:
+        counts = [700_000, 1, 2_000_000, 300]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    n = offs[-1]
+    if case == "large_ties":
+        lg = (rng.integers(-50, 50, n) / 8).astype(np.float32)
+    else:
+        lg = rng.normal(size=n).astype(np.float32)
+    k = [int(c * f) for c, f in zip(counts, rng.random(len(counts)))]
+    keep = rt.topk_prune(dev(rt, lg), offs, k)
+    assert np.array_equal(host(keep).view(np.uint32), oracle.topk(lg, offs, k))
+
+
 # ---------------------------------------------------------------- entropy kernels
 def test_factorized_quant_dequant(rt, oracle):
     rng = np.random.default_rng(21)
