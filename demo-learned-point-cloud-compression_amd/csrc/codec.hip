@@ -902,21 +902,31 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_TRY(pcc_gaussian_quant16(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
                                    ntab, sym16, idx8, flag));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
-    // one copy + one event per quality: the stream of quality q is coded (on its own thread) as soon as its
-    // symbols have crossed PCIe, while the copies of the later qualities are still in flight
-    std::vector<Event> evq_own((size_t)n_q);
-    std::vector<hipEvent_t> evq((size_t)n_q, nullptr);
-    for (int q = 0; q < n_q; ++q) {
-      if (ny > 0) {
-        PCC_HIP(hipMemcpyAsync(cd->pin_ysym.p + (size_t)q * per * 2, sym16 + (size_t)q * per, (size_t)per * 2,
-                               hipMemcpyDeviceToHost, st));
-        PCC_HIP(hipMemcpyAsync(cd->pin_yidx.p + (size_t)q * per, idx8 + (size_t)q * per, (size_t)per,
-                               hipMemcpyDeviceToHost, st));
+    // The Q streams are coded on Q host threads, and rANS codes from the END of the array: the symbols cross PCIe
+    // in kChunks pieces, last piece first (one strided copy moves that piece of every quality), and a coder only
+    // waits for the piece it is about to enter — all Q threads start after the first ~2 MB instead of after their
+    // whole quality (the last thread used to start 0.2 ms after the quantiser finished).
+    const int n_chunks = per >= (1 << 16) ? 4 : 1;
+    std::vector<int64_t> bound((size_t)n_chunks);
+    for (int c = 0; c < n_chunks; ++c) bound[c] = (per * (n_chunks - 1 - c) / n_chunks) & ~(int64_t)63;
+    std::vector<Event> ev_own((size_t)n_chunks);
+    std::vector<hipEvent_t> evc((size_t)n_chunks, nullptr);
+    for (int c = 0; c < n_chunks; ++c) {
+      const int64_t lo = bound[c], hi = c == 0 ? per : bound[c - 1];
+      if (ny > 0 && hi > lo) {
+        PCC_HIP(hipMemcpy2DAsync(cd->pin_ysym.p + (size_t)lo * 2, (size_t)per * 2, sym16 + lo, (size_t)per * 2,
+                                 (size_t)(hi - lo) * 2, (size_t)n_q, hipMemcpyDeviceToHost, st));
+        PCC_HIP(hipMemcpy2DAsync(cd->pin_yidx.p + (size_t)lo, (size_t)per, idx8 + lo, (size_t)per, (size_t)(hi - lo),
+                                 (size_t)n_q, hipMemcpyDeviceToHost, st));
       }
-      PCC_REQUIRE(evq_own[q].create() == PCC_OK, PCC_E_HIP, "pcc_encode_gop: hipEventCreate failed");
-      evq[q] = evq_own[q].e;
-      PCC_HIP(hipEventRecord(evq[q], st));
+      PCC_REQUIRE(ev_own[c].create() == PCC_OK, PCC_E_HIP, "pcc_encode_gop: hipEventCreate failed");
+      evc[c] = ev_own[c].e;
+      PCC_HIP(hipEventRecord(evc[c], st));
     }
+    struct GateUser {
+      hipEvent_t* ev;
+      bool failed;
+    };
     std::vector<int64_t> lens((size_t)n_q, 0);
     std::vector<uint8_t> stage;
     int rc = PCC_OK;
@@ -925,7 +935,15 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     std::vector<std::string> errq((size_t)n_q);
     auto code_quality = [&](int q) {
       (void)hipSetDevice(cd->device);
-      if (hipEventSynchronize(evq[q]) != hipSuccess) {
+      GateUser gu{evc.data(), false};
+      PccRansGate gate{n_chunks, bound.data(),
+                       [](void* u, int c) {
+                         GateUser* g = (GateUser*)u;
+                         if (hipEventSynchronize(g->ev[c]) != hipSuccess) g->failed = true;
+                       },
+                       &gu};
+      gate.fn(&gu, 0);  // the overflow flag travels ahead of the first piece
+      if (gu.failed) {
         rcq[q] = PCC_E_HIP;
         errq[q] = "hipEventSynchronize failed";
         return;
@@ -934,14 +952,21 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       int64_t capq = cap, got = 0;
       for (int attempt = 0; attempt < 2; ++attempt) {
         y_strings[q].resize((size_t)capq);
-        rcq[q] = pcc_rans_encode_multi16((const int16_t*)cd->pin_ysym.p + (size_t)q * per, cd->pin_yidx.p + (size_t)q * per,
-                                         per, 1, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(),
-                                         (int)gc_cdf->dims[0], y_strings[q].data(), capq, &got);
+        rcq[q] = pcc_rans_encode16_gated((const int16_t*)cd->pin_ysym.p + (size_t)q * per,
+                                         cd->pin_yidx.p + (size_t)q * per, per, gc_cdf->i32(), (int)gc_cdf->dims[1],
+                                         gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], y_strings[q].data(), capq,
+                                         &got, &gate);
         if (rcq[q] != PCC_E_NOMEM) break;
         capq = 48 * per + 4096;
       }
-      if (rcq[q] == PCC_OK) y_strings[q].resize((size_t)got);
-      else errq[q] = pcc_last_error();
+      if (rcq[q] == PCC_OK && gu.failed) {
+        rcq[q] = PCC_E_HIP;
+        errq[q] = "hipEventSynchronize failed";
+      } else if (rcq[q] == PCC_OK) {
+        y_strings[q].resize((size_t)got);
+      } else {
+        errq[q] = pcc_last_error();
+      }
     };
     {
       struct JoinAll {  // joins whatever was started, also when starting a later thread throws
@@ -1217,9 +1242,30 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
         PCC_TRY(up_of(cd, ycs, &c0));
         PCC_TRY(nbr27_of(cd, pcc_conv_up_fused() ? ycs : c0, &nbr0));
       }
-      PCC_TRY(pcc_rans_decode8(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(),
-                               gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p));
-      PCC_HIP(hipMemcpyAsync(sym_d, cd->pin_dec.p, (size_t)tot * 4, hipMemcpyHostToDevice, st));
+      // the decoded symbols go back to the device in pieces while the host is still decoding the next piece
+      const int n_chunks = tot >= (1 << 16) ? 4 : 1;
+      std::vector<int64_t> bound((size_t)n_chunks);
+      for (int c = 0; c < n_chunks; ++c) bound[c] = c == n_chunks - 1 ? tot : (tot * (c + 1) / n_chunks) & ~(int64_t)63;
+      struct UpUser {
+        const int64_t* bound;
+        const uint8_t* host;
+        int32_t* dev;
+        hipStream_t st;
+        bool failed;
+      } up{bound.data(), cd->pin_dec.p, sym_d, st, false};
+      PccRansGate gate{n_chunks, bound.data(),
+                       [](void* u, int c) {
+                         UpUser* g = (UpUser*)u;
+                         const int64_t lo = c == 0 ? 0 : g->bound[c - 1], hi = g->bound[c];
+                         if (hi > lo && hipMemcpyAsync(g->dev + lo, g->host + (size_t)lo * 4, (size_t)(hi - lo) * 4,
+                                                       hipMemcpyHostToDevice, g->st) != hipSuccess)
+                           g->failed = true;
+                       },
+                       &up};
+      PCC_TRY(pcc_rans_decode8_gated(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1],
+                                     gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p,
+                                     &gate));
+      PCC_REQUIRE(!up.failed, PCC_E_HIP, "pcc_decode_gop: hipMemcpyAsync of decoded symbols failed");
       PCC_TRY(pcc_gaussian_dequant(ctx, sym_d, params, ny, cy, scale_d, tab->f32()[0], ab->f32()[0], ab->f32()[1], rows));
     }
     float* yf;

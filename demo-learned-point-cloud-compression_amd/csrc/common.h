@@ -71,6 +71,8 @@ struct PccProfScope {
   ~PccProfScope();
 };
 
+#include "rans_gate.h"
+
 // True when pcc_sparse_conv_head_up has a kernel to run (the row-compacting MFMA family is selected and
 // PCC_CONV_UP=0 is not set); the whole-GOP decoder otherwise materialises the child rule books.
 bool pcc_conv_up_fused();

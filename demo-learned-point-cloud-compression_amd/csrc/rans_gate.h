@@ -1,0 +1,23 @@
+// rans_gate.h — internal (not part of the C-ABI): chunk gates of the host rANS coders.
+#pragma once
+#include <stdint.h>
+
+// Host rANS coders working through a buffer that is still crossing PCIe (rans_host.cpp; used by codec.hip).
+// The flattened symbol array is cut into chunks; `fn(user, c)` is called
+//   encoder: BEFORE the first access to chunk c — chunks are visited from the end of the array to its start:
+//            chunk c = [bound[c], c == 0 ? n : bound[c-1]), bound descending, bound[n_chunks-1] == 0;
+//   decoder: AFTER the last symbol of chunk c has been written — chunks in array order:
+//            chunk c = [c == 0 ? 0 : bound[c-1], bound[c]), bound ascending, bound[n_chunks-1] == n.
+struct PccRansGate {
+  int n_chunks;
+  const int64_t* bound;
+  void (*fn)(void* user, int chunk);
+  void* user;
+};
+int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                            uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate);
+int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                           int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                           int32_t* h_sym, const PccRansGate* gate);
+

@@ -29,6 +29,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/pcc.h"
+#include "rans_gate.h"
 
 void pcc_set_error(const char* fmt, ...);
 
@@ -87,7 +88,7 @@ inline int n_nibbles(uint32_t raw) {
 template <typename SymT, typename IdxT>
 int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cdfs, int pitch,
                   const int32_t* sizes, const int32_t* offsets, int n_cdf, uint8_t* out, int64_t cap,
-                  int64_t* len, char* err, size_t errlen) {
+                  int64_t* len, char* err, size_t errlen, const PccRansGate* gate = nullptr) {
   // worst case per symbol: 1 main step + (1..2 unary) + 8 raw nibbles; each step emits at most
   // one 32-bit word, and in-range symbols (the common case) emit 16 bits on average.  Size the
   // staging buffer for the common case and grow on demand.
@@ -129,7 +130,11 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
     e.floor = buf.data();
     e.ptr = buf.data() + buf.size();
     e.overflow = false;
-    for (int64_t i = n - 1; i >= 0; --i) {
+    const int n_chunks = gate ? gate->n_chunks : 1;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+    const int64_t i_hi = (ch == 0 ? n : gate->bound[ch - 1]) - 1, i_lo = gate ? gate->bound[ch] : 0;
+    if (gate) gate->fn(gate->user, ch);  // chunk ch has arrived (returns at once on a second attempt)
+    for (int64_t i = i_hi; i >= i_lo; --i) {
       const int32_t ci = (int32_t)idx[i];
       if ((uint32_t)ci >= (uint32_t)n_cdf) {
         snprintf(err, errlen, "rans encode: index %d out of range at %lld", ci, (long long)i);
@@ -156,6 +161,7 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
         return PCC_E_ARG;
       }
       e.put(es);
+    }
     }
     // flush: two words, low then high
     e.emit((uint32_t)(e.x >> 32));
@@ -219,7 +225,7 @@ constexpr int kLutBits = 10;
 template <typename IdxT>
 int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n, const int32_t* h_cdfs,
                   int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, int32_t* h_sym,
-                  const char* who) {
+                  const char* who, const PccRansGate* gate = nullptr) {
   if (!h_in || len < 8 || n < 0 || (n > 0 && (!h_idx || !h_sym)) || !h_cdfs || !h_sizes || !h_offsets ||
       cdf_pitch < 2 || n_cdf < 1) {
     pcc_set_error("%s: bad argument (len=%lld)", who, (long long)len);
@@ -288,7 +294,10 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
   bool bad = false;
   uint64_t x = word(bad);
   x |= (uint64_t)word(bad) << 32;
-  for (int64_t i = 0; i < n; ++i) {
+  const int n_chunks = gate ? gate->n_chunks : 1;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+  const int64_t i_lo = ch == 0 ? 0 : gate->bound[ch - 1], i_hi = gate ? gate->bound[ch] : n;
+  for (int64_t i = i_lo; i < i_hi; ++i) {
     const DecTab& t = tabs[(size_t)(int32_t)h_idx[i]];
     const uint32_t cum = (uint32_t)(x & 0xFFFFu);
     const uint64_t l = t.lut[cum >> (16 - kLutBits)];
@@ -327,6 +336,8 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
     }
     h_sym[i] = value + t.offset;
   }
+  if (gate && !bad) gate->fn(gate->user, ch);  // chunk ch is complete
+  }
   if (bad) {
     pcc_set_error("%s: truncated stream", who);
     return PCC_E_STREAM;
@@ -335,6 +346,42 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
 }
 
 }  // namespace
+
+static bool gate_ok(const PccRansGate* g, int64_t n, bool descending) {
+  if (!g) return true;
+  if (g->n_chunks < 1 || !g->bound || !g->fn) return false;
+  for (int c = 0; c < g->n_chunks; ++c) {
+    const int64_t b = g->bound[c], prev = c == 0 ? (descending ? n : 0) : g->bound[c - 1];
+    if (b < 0 || b > n || (descending ? b > prev : b < prev)) return false;
+  }
+  return g->bound[g->n_chunks - 1] == (descending ? 0 : n);
+}
+
+int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                            uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate) {
+  if (!h_len || n < 0 || (n > 0 && (!h_sym || !h_idx)) || !h_cdfs || !h_sizes || !h_offsets || !h_out ||
+      cdf_pitch < 2 || n_cdf < 1 || !gate_ok(gate, n, true)) {
+    pcc_set_error("pcc_rans_encode16_gated: bad argument");
+    return PCC_E_ARG;
+  }
+  char err[256] = {0};
+  const int rc = encode_stream(h_sym, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out, cap, h_len, err,
+                               sizeof(err), gate);
+  if (rc != PCC_OK) pcc_set_error("pcc_rans_encode16_gated: %s", err);
+  return rc;
+}
+
+int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                           int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                           int32_t* h_sym, const PccRansGate* gate) {
+  if (!gate_ok(gate, n, false)) {
+    pcc_set_error("pcc_rans_decode8_gated: bad chunk table");
+    return PCC_E_ARG;
+  }
+  return decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
+                       "pcc_rans_decode8", gate);
+}
 
 extern "C" int pcc_rans_encode(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
                                const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
