@@ -195,6 +195,56 @@ def test_rans_compact_widths_equal_generic(oracle):
         assert np.array_equal(runtime.rans_decode(a[s], idx[s], cdf, sizes, offs), sym[s])
 
 
+def test_rans_gated_coders_equal_the_plain_ones(oracle):
+    """the chunk-gated forms the native codec uses to overlap PCIe with coding (rans_gate.h: internal C++ entry
+    points, bound here by their mangled names): same bytes / symbols as the plain calls, and the gate fires once
+    per chunk — the encoder BEFORE it enters a chunk, from the last chunk to the first; the decoder AFTER it has
+    finished one, in array order"""
+    import ctypes as C
+    runtime = pkg("runtime")
+    lib = pkg("_abi").lib()
+    cdf, sizes, offs = _tables(oracle, "gaussian_conditional")
+    rng = np.random.default_rng(6)
+    n = 100_000
+    sym = rng.integers(-9, 10, n).astype(np.int16)
+    sym[::997] = 2000                                  # escapes
+    idx = rng.integers(0, 64, n).astype(np.uint8)
+    ref = runtime.rans_encode_multi(sym[None], idx[None], cdf, sizes, offs)[0]
+
+    class Gate(C.Structure):
+        _fields_ = [("n_chunks", C.c_int), ("bound", C.POINTER(C.c_int64)), ("fn", C.c_void_p), ("user", C.c_void_p)]
+    FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+    calls = []
+    cb = FN(lambda user, c: calls.append(c))
+    enc = getattr(lib, "_Z23pcc_rans_encode16_gatedPKsPKhlPKiiS4_S4_iPhlPlPK11PccRansGate")
+    dec = getattr(lib, "_Z22pcc_rans_decode8_gatedPKhlS0_lPKiiS2_S2_iPiPK11PccRansGate")
+    enc.restype = dec.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    cdf32, sz32, of32 = (np.ascontiguousarray(a, np.int32) for a in (cdf, sizes, offs))
+
+    bound = (C.c_int64 * 4)(75_008, 50_048, 1, 0)      # descending chunk starts, last one a single symbol
+    g = Gate(4, bound, C.cast(cb, C.c_void_p), None)
+    out = np.zeros(4 * n, np.uint8)
+    got = C.c_int64(0)
+    rc = enc(p(sym), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32), C.c_int(len(sz32)),
+             p(out), C.c_int64(out.size), C.byref(got), C.byref(g))
+    assert rc == 0 and bytes(out[:got.value]) == ref and calls == [0, 1, 2, 3]
+
+    calls.clear()
+    bound = (C.c_int64 * 3)(64, 99_999, n)              # ascending chunk ends
+    g = Gate(3, bound, C.cast(cb, C.c_void_p), None)
+    dsym = np.zeros(n, np.int32)
+    src = np.frombuffer(ref, np.uint8)
+    rc = dec(p(src), C.c_int64(src.size), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32),
+             C.c_int(len(sz32)), p(dsym), C.byref(g))
+    assert rc == 0 and np.array_equal(dsym, sym.astype(np.int32)) and calls == [0, 1, 2]
+    # a chunk table that does not cover the array is refused
+    bad = (C.c_int64 * 2)(10, n - 1)
+    g = Gate(2, bad, C.cast(cb, C.c_void_p), None)
+    assert dec(p(src), C.c_int64(src.size), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32),
+               C.c_int(len(sz32)), p(dsym), C.byref(g)) != 0
+
+
 def test_rans_decode_rejects_truncated(oracle):
     runtime = pkg("runtime")
     cdf, sizes, offs = _tables(oracle, "gaussian_conditional")
