@@ -235,13 +235,24 @@ def main():
             kname = {"sparse_conv": "k_gconv_mfma", "convT_gen": "k_convT_mfma"}[op]
             # grid of the dense-tile kernels (4 waves x 32 rows) or of the row-compacting one (1 wave x 64 rows)
             # (its grid is rounded up to a multiple of 8 workgroups for the per-XCD window order)
-            grids = (((n_out + 127) // 128) * 256, ((n_out + 63) // 64) * 64, ((n_out + 63) // 64 + 7) // 8 * 8 * 64)
+            grids = (((n_out + 127) // 128) * 256, ((n_out + 63) // 64) * 64, ((n_out + 63) // 64 + 7) // 8 * 8 * 64,
+                     ((n_out + 255) // 256 + 7) // 8 * 8 * 256)
             recs = [r for r in pmc["kernels"] if kname in r["kernel"] and r["grid_threads"] in grids]
             # the timed (native) engine runs the g_s convs in the form that makes the child rule book in-kernel
-            # (<.., UP=true>); the PMC passes also hold the explicit form from the op-by-op pairs count
-            fused = [r for r in recs if "true, true>" in r["kernel"]]
-            if fused and os.environ.get("PCC_CONV_UP") != "0":
-                recs = fused
+            # (<.., UP=true>), on the four-windows-per-workgroup kernel for layers of this size (_w4); the PMC passes
+            # also hold the explicit-rule-book form from the op-by-op pairs count
+            prefer = []
+            if os.environ.get("PCC_CONV_UP") != "0":
+                if os.environ.get("PCC_CONV_W4") != "0":
+                    prefer.append("_w4<true, true>")
+                prefer.append("<1, true, true>")
+            if os.environ.get("PCC_CONV_W4") != "0":
+                prefer.append("_w4<")
+            for tag in prefer:
+                hit = [r for r in recs if tag in r["kernel"]]
+                if hit:
+                    recs = hit
+                    break
             if recs:
                 roofline["traffic"] = recs[0]["hbm_bytes_corrected"]
                 roofline["traffic_kernel"] = recs[0]["kernel"].split("(")[0]

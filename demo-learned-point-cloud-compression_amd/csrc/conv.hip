@@ -421,12 +421,24 @@ bool pcc_conv_up_fused() {
   return !off && !force_scalar() && !conv_simple() && compact_rows() != 0;
 }
 
+// Layers of >= 200k rows run four 64-row windows per workgroup with the weights shared through LDS (conv_compact.h:
+// -3 % on the 3.26M-row layer); smaller launches are one round of windows, where the per-offset workgroup barrier
+// only lengthens the critical path.  PCC_CONV_W4=0 keeps every layer on the one-window-per-workgroup kernel, =1 forces
+// the shared form for every size (tests).
+static bool conv_w4(int64_t n_out) {
+  static const int mode = [] { const char* e = getenv("PCC_CONV_W4"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  return mode < 0 ? n_out >= 200000 : mode == 1;
+}
+
 template <bool HEAD>
 static void launch_compact(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
                            int64_t n_out, const float* d_w, const float* d_bias, int relu, float* d_out,
                            const float* hw, const float* hb, float* ho) {
   // grid rounded up to a multiple of 8: the kernel maps workgroup -> window per XCD
-  if (compact_rows() == 64)
+  if (compact_rows() == 64 && conv_w4(n_out))
+    hipLaunchKernelGGL((k_gconv_mfma_compact_w4<HEAD, false>), dim3((nblk(n_out, 256) + 7) / 8 * 8), dim3(256), 0, st,
+                       d_in, d_nbr, k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
+  else if (compact_rows() == 64)
     hipLaunchKernelGGL((k_gconv_mfma_compact<1, HEAD>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0, st, d_in,
                        d_nbr, k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
   else
@@ -520,9 +532,14 @@ extern "C" int pcc_sparse_conv_head_up(pcc_ctx* ctx, const float* d_in, int64_t 
               "PCC_CONV_SIMPLE / PCC_CONV_COMPACT=0 / PCC_CONV_UP=0 select the explicit rule book: pcc_derive_map_up)");
   const int64_t n_out = 8 * n_parents;
   PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
-  hipLaunchKernelGGL((k_gconv_mfma_compact<1, true, true>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0,
-                     ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
-                     d_head_b, d_head_out);
+  if (conv_w4(n_out))
+    hipLaunchKernelGGL((k_gconv_mfma_compact_w4<true, true>), dim3((nblk(n_out, 256) + 7) / 8 * 8), dim3(256), 0,
+                       ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
+                       d_head_b, d_head_out);
+  else
+    hipLaunchKernelGGL((k_gconv_mfma_compact<1, true, true>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0,
+                       ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
+                       d_head_b, d_head_out);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

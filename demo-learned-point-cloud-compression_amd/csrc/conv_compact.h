@@ -37,6 +37,7 @@
 // lower occupancy).  Variants that were measured and dropped: gathered rows staged through an LDS
 // tile (1.70 ms: 16 ds_write + 16 ds_read per group), compaction by ds_permute with the slot lists in
 // registers (1.83-1.87 ms) and a single weight register set reloaded behind its last reader (1.72 ms).
+// Layers of >= 200k rows run k_gconv_mfma_compact_w4 at the end of this file (weights shared through LDS).
 #pragma once
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -231,4 +232,198 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
     }
   }
 #undef PCC_WAVE_SYNC
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Four windows per workgroup, weights shared through LDS.
+//
+// In the kernel above every wave fetches the 4 KB weight matrix of every offset for itself: as many bytes through
+// the texture path as its useful gathered rows.  With the weight loads removed that kernel runs 14 % faster
+// (ablation, tools/bench_conv.py: 1.61 -> 1.38 ms on the 3.26M-row layer).  Here a workgroup is four such waves
+// (four consecutive 64-row windows); each wave fetches a QUARTER of W[k+2] (one dwordx4 per lane), the quarters meet
+// in a double-buffered LDS tile, and every wave reads its MFMA operands of W[k] from there.  One s_barrier per
+// offset; it waits for LDS only (lgkmcnt), never for the gathers in flight.
+//   iteration k:  bc <- wbuf[k & 1]            (W[k]: complete since the barrier that closed iteration k-1)
+//                 wbuf[(k+1) & 1] <- wq        (own quarter of W[k+1]; every wave read W[k-1] from it before that barrier)
+//                 wq <- global quarter of W[k+2]
+//                 ... compact / gather / contract as above ...
+//                 barrier
+template <bool HEAD, bool UP = false>
+__global__ __launch_bounds__(256) void k_gconv_mfma_compact_w4(
+    const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+    int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
+    float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ head_out) {
+  constexpr int RCH = 1;
+  constexpr int R = 64;
+  constexpr int AP = 36;
+  __shared__ __attribute__((aligned(16))) float acc_all[4][(R + 1) * AP];
+  __shared__ int32_t slot_in_all[4][2][R];
+  __shared__ uint8_t slot_row_all[4][2][R];
+  __shared__ __attribute__((aligned(16))) float wbuf[2][32 * 32];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const acc_lds = acc_all[wave];
+  int32_t(*const slot_in)[R] = slot_in_all[wave];
+  uint8_t(*const slot_row)[R] = slot_row_all[wave];
+  // XCD-aware order over workgroups (see above); a workgroup owns four consecutive windows.  A wave whose window
+  // lies past the end keeps running (all rows absent): the others need its quarter of the weights and its barriers
+  const int64_t wg = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t row0 = (wg * 4 + wave) * R;
+  const int i = lane & 31, h = lane >> 5;
+  const int grow = lane >> 3, chunk = lane & 7;
+
+  {
+    const float4 b4 = make_float4(bias[chunk * 4], bias[chunk * 4 + 1], bias[chunk * 4 + 2], bias[chunk * 4 + 3]);
+#pragma unroll
+    for (int it = 0; it < R / 8; ++it)
+      *reinterpret_cast<float4*>(&acc_lds[(it * 8 + grow) * AP + chunk * 4]) = b4;
+    if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[R * AP + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  int32_t nbreg[RCH];
+  auto load_nb = [&](int k) {
+    const int64_t r = row0 + lane;
+    const int kk = k < k_vol ? k : k_vol - 1;
+    const int64_t rc = r < n_out ? r : n_out - 1;
+    if constexpr (UP) {
+      const int o = (int)(rc & 7);
+      const int tx = ((o >> 2) & 1) + (kk / 9) - 1, ty = ((o >> 1) & 1) + ((kk / 3) % 3) - 1, tz = (o & 1) + (kk % 3) - 1;
+      const int kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
+      const int op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+      const int32_t pr = nbr[(int64_t)kp * pitch + (rc >> 3)];
+      nbreg[0] = (k < k_vol && r < n_out && pr >= 0) ? ((pr << 3) | op) : -1;
+    } else {
+      const int32_t v = nbr[(int64_t)kk * pitch + rc];
+      nbreg[0] = (k < k_vol && r < n_out) ? v : -1;
+    }
+  };
+  auto compact = [&](int b) -> int {
+    const bool p = nbreg[0] >= 0;
+    const unsigned long long bal = __ballot(p);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    const int cnt = __popcll(bal);
+    if (p) {
+      slot_in[b][rank] = nbreg[0];
+      slot_row[b][rank] = (uint8_t)lane;
+    }
+    const int sl = cnt + lane;
+    if (sl < R) {
+      slot_in[b][sl] = 0;
+      slot_row[b][sl] = (uint8_t)R;
+    }
+    return cnt;
+  };
+
+  constexpr int NG = R / 32;
+  float4 gA[NG][4], gB[NG][4];
+  // this thread's 16 B of a weight matrix: quarter `wave`, float4 index `lane` of it
+  float4 wq;
+  auto load_wq = [&](int k) {
+    const int kk = k < k_vol ? k : k_vol - 1;
+    wq = *reinterpret_cast<const float4*>(w + (int64_t)kk * 1024 + threadIdx.x * 4);
+  };
+
+#define PCC_WAVE_SYNC()                                      \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+// workgroup barrier that waits for this wave's LDS traffic only: loads in flight (gathers, next weights, next
+// neighbour indices) stay in flight across it
+#define PCC_WG_SYNC()                                        \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */     \
+    __builtin_amdgcn_s_barrier();                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+#define PCC_GATHER(G, b)                                                                           \
+  do {                                                                                             \
+    _Pragma("unroll") for (int grp = 0; grp < NG; ++grp) {                                         \
+      const float* xr = in + (int64_t)slot_in[b][grp * 32 + i] * 32 + h * 16;                      \
+      _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
+        G[grp][it] = *reinterpret_cast<const float4*>(xr + it * 4);                                \
+    }                                                                                              \
+  } while (0)
+#define PCC_STEP(GC, GN, cur, k)                                                                   \
+  do {                                                                                             \
+    const int cnt_next = compact((cur) ^ 1);                                                       \
+    load_nb((k) + 2);                                                                              \
+    *reinterpret_cast<float4*>(&wbuf[((k) + 1) & 1][threadIdx.x * 4]) = wq;                        \
+    load_wq((k) + 2);                                                                              \
+    PCC_WAVE_SYNC();                                                                               \
+    PCC_GATHER(GN, (cur) ^ 1);                                                                     \
+    float bc[16]; /* read behind the gathers' issue: its LDS latency overlaps the accumulator reads */ \
+    _Pragma("unroll") for (int s = 0; s < 16; ++s) bc[s] = wbuf[(k) & 1][(2 * s + h) * 32 + i];    \
+    _Pragma("unroll") for (int grp = 0; grp < NG; ++grp) {                                         \
+      if (grp * 32 < cnt_cur) {                                                                    \
+        const int arow = (int)slot_row[cur][grp * 32 + i];                                         \
+        float* ap = &acc_lds[arow * AP + h * 4];                                                   \
+        f32x16 acc;                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+          const float4 c4 = *reinterpret_cast<const float4*>(ap + j * 8);                          \
+          acc[4 * j + 0] = c4.x; acc[4 * j + 1] = c4.y; acc[4 * j + 2] = c4.z; acc[4 * j + 3] = c4.w; \
+        }                                                                                          \
+        float xv[16];                                                                              \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                         \
+          const u32x2 p0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(GC[grp][it].x),        \
+                                                            __float_as_uint(GC[grp][it].y), false, false); \
+          const u32x2 p1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(GC[grp][it].z),        \
+                                                            __float_as_uint(GC[grp][it].w), false, false); \
+          xv[2 * it] = __uint_as_float(p0[0]);     xv[8 + 2 * it] = __uint_as_float(p0[1]);        \
+          xv[2 * it + 1] = __uint_as_float(p1[0]); xv[8 + 2 * it + 1] = __uint_as_float(p1[1]);    \
+        }                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 16; ++s)                                             \
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s], xv[s], acc, 0, 0, 0);                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+          *reinterpret_cast<float4*>(ap + j * 8) =                                                 \
+              make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);         \
+        PCC_WAVE_SYNC();                                                                           \
+      }                                                                                            \
+    }                                                                                              \
+    cnt_cur = cnt_next;                                                                            \
+    PCC_WG_SYNC();                                                                                 \
+  } while (0)
+
+  load_nb(0);
+  int cnt_cur = compact(0);
+  load_nb(1);
+  load_wq(0);
+  *reinterpret_cast<float4*>(&wbuf[0][threadIdx.x * 4]) = wq;
+  load_wq(1);
+  PCC_WG_SYNC();
+  PCC_GATHER(gA, 0);
+
+  for (int k = 0; k < k_vol; k += 2) {
+    PCC_STEP(gA, gB, 0, k);
+    if (k + 1 < k_vol) PCC_STEP(gB, gA, 1, k + 1);
+  }
+#undef PCC_STEP
+#undef PCC_GATHER
+
+#pragma unroll
+  for (int it = 0; it < R / 8; ++it) {
+    const int r = it * 8 + grow;
+    float4 v = *reinterpret_cast<const float4*>(&acc_lds[r * AP + chunk * 4]);
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
+  }
+  if constexpr (HEAD) {
+    const int r = lane;
+    float hv = head_b[0];
+#pragma unroll
+    for (int ch = 0; ch < 32; ++ch) {
+      float v = acc_lds[r * AP + ch];
+      if (relu) v = fmaxf(v, 0.f);
+      hv = fmaf(v, head_w[ch], hv);
+    }
+    if (row0 + r < n_out) head_out[row0 + r] = hv;
+  }
+#undef PCC_WAVE_SYNC
+#undef PCC_WG_SYNC
 }

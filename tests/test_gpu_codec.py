@@ -232,9 +232,12 @@ def test_conv_kernel_families_agree_end_to_end(wl):
         "[h.update(f['points'].tobytes() + f['colors'].tobytes()) for f in r];"
         "print(h.hexdigest())" % ROOT)
     res = []
-    for mode in ("64", "128", "0", "up0"):  # up0: 64-row windows with the explicit child rule books
-        env = dict(os.environ, PCC_CONV_UP="0") if mode == "up0" else dict(os.environ, PCC_CONV_COMPACT=mode)
+    # up0: 64-row windows with the explicit child rule books; w4_0 / w4_1: weights per wave / shared through LDS by
+    # the four waves of a workgroup, for every layer size
+    for mode in ("64", "128", "0", "up0", "w4_0", "w4_1"):
+        env = {"up0": dict(os.environ, PCC_CONV_UP="0"), "w4_0": dict(os.environ, PCC_CONV_W4="0"),
+               "w4_1": dict(os.environ, PCC_CONV_W4="1")}.get(mode) or dict(os.environ, PCC_CONV_COMPACT=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])
-    assert res[0] == res[1] == res[2] == res[3]
+    assert len(set(res)) == 1, res

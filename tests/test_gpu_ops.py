@@ -428,6 +428,21 @@ def test_conv_head_up_refuses_when_family_is_off(rt):
         assert want in out.stdout, (env, out.stdout, out.stderr[-400:])
 
 
+def test_conv_ops_on_the_shared_weight_kernel():
+    """layers of >= 200k rows run four windows per workgroup with the weights shared through LDS; the op tests above
+    are far smaller, so they are run once more in a child process with PCC_CONV_W4=1 (that kernel for every size:
+    windows / quarter-workgroups past the end, K = 8 and 27, fused head, in-kernel rule book, pitch)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-k",
+                        "row_compaction or conv_head_up_forms or pitch_and_foreign or sparse_conv_down or "
+                        "sparse_conv3_bit_exact"],
+                       env=dict(os.environ, PCC_CONV_W4="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):
     """n_in != n_out (stride-2 conv: 8 offsets, input = children, output = parents) and a rule book whose
     row pitch is larger than n_out: the kernel must honour the pitch and never read past n_out"""
