@@ -430,6 +430,15 @@ static bool conv_w4(int64_t n_out) {
   return mode < 0 ? n_out >= 200000 : mode == 1;
 }
 
+// Launches of at most 64k rows use 32-row windows: such a launch is one partial round of windows and lasts as long as
+// ONE window's 27 dependent offset steps, which are shorter with a single 32-slot group each (26k rows: 49 -> 34 us;
+// at 106k rows the half windows no longer fit one round: 68 -> 86 us).  PCC_CONV_HALFW=0 disables, =1 extends the rule
+// to every launch below 200k rows (tests).
+static bool conv_halfw(int64_t n_out) {
+  static const int mode = [] { const char* e = getenv("PCC_CONV_HALFW"); return e ? atoi(e) : -1; }();
+  return mode < 0 ? n_out <= 65536 : (mode == 1 && n_out < 200000);
+}
+
 template <bool HEAD>
 static void launch_compact(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
                            int64_t n_out, const float* d_w, const float* d_bias, int relu, float* d_out,
@@ -437,6 +446,9 @@ static void launch_compact(hipStream_t st, const float* d_in, const int32_t* d_n
   // grid rounded up to a multiple of 8: the kernel maps workgroup -> window per XCD
   if (compact_rows() == 64 && conv_w4(n_out))
     hipLaunchKernelGGL((k_gconv_mfma_compact_w4<HEAD, false>), dim3((nblk(n_out, 256) + 7) / 8 * 8), dim3(256), 0, st,
+                       d_in, d_nbr, k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
+  else if (compact_rows() == 64 && conv_halfw(n_out))
+    hipLaunchKernelGGL((k_gconv_mfma_compact<1, HEAD, false, true>), dim3((nblk(n_out, 32) + 7) / 8 * 8), dim3(64), 0, st,
                        d_in, d_nbr, k_vol, pitch, n_out, d_w, d_bias, relu, d_out, hw, hb, ho);
   else if (compact_rows() == 64)
     hipLaunchKernelGGL((k_gconv_mfma_compact<1, HEAD>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0, st, d_in,

@@ -46,13 +46,16 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // the parent level's rule book: the child's neighbour at offset k is child o' of parent-neighbour kp (per axis
 // t = o + d, D = floor(t / 2), o' = t & 1 — pcc_derive_map_up's rule), formed here from one parent-book load, so
 // the 27 x 8N child rule book is never written to or read from HBM.
-template <int RCH, bool HEAD, bool UP = false>
+// HALFW: 32-row windows (lanes 32..63 own no row): every offset is ONE group, so a window's 27 dependent steps are
+// shorter — for launches of a single round of windows, whose duration is one window's latency, not throughput.
+template <int RCH, bool HEAD, bool UP = false, bool HALFW = false>
 __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
     float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
     float* __restrict__ head_out) {
-  constexpr int R = 64 * RCH;  // output rows of this wave
+  static_assert(!HALFW || RCH == 1, "half windows are a variant of the 64-row kernel");
+  constexpr int R = HALFW ? 32 : 64 * RCH;  // output rows of this wave
   constexpr int AP = 36;       // accumulator row pitch (floats), 16-B aligned rows
   __shared__ __attribute__((aligned(16))) float acc_lds[(R + 1) * AP];  // row R = sink for pad slots
   __shared__ int32_t slot_in[2][R];
@@ -90,10 +93,10 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
         const int kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
         const int op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
         const int32_t pr = nbr[(int64_t)kp * pitch + (rc >> 3)];
-        nbreg[c] = (k < k_vol && r < n_out && pr >= 0) ? ((pr << 3) | op) : -1;
+        nbreg[c] = (k < k_vol && r < n_out && pr >= 0 && (!HALFW || lane < 32)) ? ((pr << 3) | op) : -1;
       } else {
         const int32_t v = nbr[(int64_t)kk * pitch + rc];
-        nbreg[c] = (k < k_vol && r < n_out) ? v : -1;
+        nbreg[c] = (k < k_vol && r < n_out && (!HALFW || lane < 32)) ? v : -1;
       }
     }
   };
@@ -224,11 +227,11 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
       float hv = head_b[0];
 #pragma unroll
       for (int ch = 0; ch < 32; ++ch) {
-        float v = acc_lds[r * AP + ch];
+        float v = acc_lds[(r < R ? r : 0) * AP + ch];
         if (relu) v = fmaxf(v, 0.f);
         hv = fmaf(v, head_w[ch], hv);
       }
-      if (row0 + r < n_out) head_out[row0 + r] = hv;
+      if (row0 + r < n_out && r < R) head_out[row0 + r] = hv;
     }
   }
 #undef PCC_WAVE_SYNC

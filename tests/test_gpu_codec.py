@@ -234,9 +234,11 @@ def test_conv_kernel_families_agree_end_to_end(wl):
     res = []
     # up0: 64-row windows with the explicit child rule books; w4_0 / w4_1: weights per wave / shared through LDS by
     # the four waves of a workgroup, for every layer size
-    for mode in ("64", "128", "0", "up0", "w4_0", "w4_1"):
+    # the same with the 32-row windows of the small layers off (half0) / used below 200k rows (half1)
+    for mode in ("64", "128", "0", "up0", "w4_0", "w4_1", "half0", "half1"):
         env = {"up0": dict(os.environ, PCC_CONV_UP="0"), "w4_0": dict(os.environ, PCC_CONV_W4="0"),
-               "w4_1": dict(os.environ, PCC_CONV_W4="1")}.get(mode) or dict(os.environ, PCC_CONV_COMPACT=mode)
+               "w4_1": dict(os.environ, PCC_CONV_W4="1"), "half0": dict(os.environ, PCC_CONV_HALFW="0"),
+               "half1": dict(os.environ, PCC_CONV_HALFW="1")}.get(mode) or dict(os.environ, PCC_CONV_COMPACT=mode)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])

@@ -435,12 +435,14 @@ def test_conv_ops_on_the_shared_weight_kernel():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-k",
-                        "row_compaction or conv_head_up_forms or pitch_and_foreign or sparse_conv_down or "
-                        "sparse_conv3_bit_exact"],
-                       env=dict(os.environ, PCC_CONV_W4="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout
+    sel = ("row_compaction or conv_head_up_forms or pitch_and_foreign or sparse_conv_down or sparse_conv3_bit_exact")
+    # second child: the one-window-per-workgroup kernel with 64-row windows at these sizes (the default gives
+    # launches of <= 64k rows 32-row windows, which is what the tests above exercise in this process)
+    for env in ({"PCC_CONV_W4": "1"}, {"PCC_CONV_HALFW": "0"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-k", sel],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, str(env) + r.stdout[-3000:] + r.stderr[-1000:]
+        assert " passed" in r.stdout
 
 
 def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):
