@@ -45,6 +45,7 @@ PROTOTYPES = {
                                     C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64, C.POINTER(C.c_double)]),
     "pcc_decode_gop": (i32, [vp, vp, i64, C.POINTER(PccCloudInfo), C.POINTER(C.c_double)]),
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
+    "pcc_decode_fetch_packed": (i32, [vp, vp, vp]),
     "pcc_sparse_conv_head_up": (i32, [vp, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp, vp]),
     "pcc_level_counts": (i32, [vp, vp, i64, i32, i32, pi64, C.POINTER(C.c_int)]),
     "pcc_down_coords_known": (i32, [vp, vp, i64, i32, vp, vp, i64, vp, i64]),

@@ -97,17 +97,15 @@ class DecompressionPipeline:
         codec = self._slots.get()
         try:
             with torch.cuda.stream(codec.stream):
-                coords, colors, offs, _, times = codec.decode(bytes(compressed_data))
                 if self.output == "device":
+                    coords, colors, offs, _, times = codec.decode(bytes(compressed_data))
                     batch = [{"points": coords[offs[i]:offs[i + 1], 1:], "colors": colors[offs[i]:offs[i + 1]]}
                              for i in range(len(offs) - 1)]
                 else:
-                    points, cols = coords.cpu().numpy(), colors.cpu().numpy()
-                    batch = []
-                    for i in range(len(offs) - 1):
-                        item_colors = np.nan_to_num(cols[offs[i]:offs[i + 1]], nan=0.0)
-                        batch.append({"points": points[offs[i]:offs[i + 1], 1:],
-                                      "colors": np.clip(item_colors * 255.0, 0, 255) / 255})
+                    # NaN -> 0 and the colour clip of pack_batches run on the device; the host only slices
+                    points, cols, offs, _, times = codec.decode(bytes(compressed_data), packed_host=True)
+                    batch = [{"points": points[offs[i]:offs[i + 1]], "colors": cols[offs[i]:offs[i + 1]]}
+                             for i in range(len(offs) - 1)]
         finally:
             self._slots.put(codec)
         sideinfo = {"time_measurements": times,

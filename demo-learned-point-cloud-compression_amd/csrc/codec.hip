@@ -1419,6 +1419,43 @@ extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, p
   }
 }
 
+// pack_batches (codec_parallel.py:474-502) on the device: xyz without the batch column, colours NaN -> 0 and
+// clip(c * 255, 0, 255) / 255 in single IEEE operations (the bits numpy's float32 expression gives)
+__global__ __launch_bounds__(256) void k_pack_cloud(const int4* __restrict__ coords, const float* __restrict__ colors,
+                                                    int64_t n, int32_t* __restrict__ xyz, float* __restrict__ rgb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  xyz[3 * i] = c.y;
+  xyz[3 * i + 1] = c.z;
+  xyz[3 * i + 2] = c.w;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = colors[3 * i + k];
+    v = (v != v) ? 0.0f : v;
+    rgb[3 * i + k] = __fdiv_rn(fminf(fmaxf(__fmul_rn(v, 255.0f), 0.0f), 255.0f), 255.0f);
+  }
+}
+
+extern "C" int pcc_decode_fetch_packed(pcc_codec* cd, int32_t* points, float* colors) {
+  PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_decode_fetch_packed: null codec");
+  if (cd->rec_n == 0) return PCC_OK;
+  PCC_REQUIRE(cd->rec_coords && cd->rec_colors && points && colors, PCC_E_ARG,
+              "pcc_decode_fetch_packed: no decoded GOP on this codec, or null destination");
+  hipStream_t st = cd->ctx->stream;
+  const int64_t n = cd->rec_n;
+  CODEC_ALLOC(xyz, int32_t, 3 * n);
+  CODEC_ALLOC(rgb, float, 3 * n);
+  hipLaunchKernelGGL(k_pack_cloud, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int4*)cd->rec_coords,
+                     (const float*)cd->rec_colors, n, xyz, rgb);
+  PCC_CHECK_LAUNCH();
+  // destinations may be device or host memory (pageable host memory is staged by the runtime)
+  PCC_HIP(hipMemcpyAsync(points, xyz, (size_t)n * 12, hipMemcpyDefault, st));
+  PCC_HIP(hipMemcpyAsync(colors, rgb, (size_t)n * 12, hipMemcpyDefault, st));
+  PCC_HIP(hipStreamSynchronize(st));
+  return PCC_OK;
+}
+
 extern "C" int pcc_decode_fetch(pcc_codec* cd, int32_t* d_coords, float* d_colors) {
   PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_decode_fetch: null codec");
   if (cd->rec_n == 0) return PCC_OK;

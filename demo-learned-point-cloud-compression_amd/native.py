@@ -128,15 +128,23 @@ class NativeCodec:
         return out, ks, dict(zip(ENC_STAGES, ts))
 
     # ------------------------------------------------------------------ decode
-    def decode(self, data):
+    def decode(self, data, packed_host=False):
         """container bytes -> (coords int32 [n,4] device, colors float32 [n,3] device, offsets, q, stage seconds).
-        The two tensors are copies owned by the caller."""
+        The two tensors are copies owned by the caller.  packed_host=True: the cloud as pack_batches returns it, in
+        host memory — (points int32 [n,3] numpy, colours float32 [n,3] numpy clipped on the device, ...)."""
         info = _abi.PccCloudInfo()
         ts = (C.c_double * 6)()
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
         check(self.lib.pcc_decode_gop(self.handle, buf, len(data), C.byref(info), ts), "pcc_decode_gop")
         n = int(info.n_points)
         offsets = [int(info.h_offsets[i]) for i in range(info.n_offsets)]
+        if packed_host:
+            pts = np.empty((n, 3), dtype=np.int32)
+            cols = np.empty((n, 3), dtype=np.float32)
+            if n:
+                check(self.lib.pcc_decode_fetch_packed(self.handle, C.c_void_p(pts.ctypes.data),
+                                                       C.c_void_p(cols.ctypes.data)), "pcc_decode_fetch_packed")
+            return pts, cols, offsets, [float(info.q_g), float(info.q_a)], dict(zip(DEC_STAGES, ts))
         coords = torch.empty((n, 4), dtype=torch.int32, device=self.device)
         colors = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         if n:

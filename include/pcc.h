@@ -467,6 +467,12 @@ int pcc_decode_gop(pcc_codec* codec, const uint8_t* h_in, int64_t len,
  * (int32 [n_points,4], float32 [n_points,3]; either may be NULL); returns when
  * the copies are complete */
 int pcc_decode_fetch(pcc_codec* codec, int32_t* d_coords, float* d_colors);
+/* the same cloud as pack_batches returns it (codec_parallel.py:474-502):
+ * points int32 [n_points,3] (no batch column; frame i = rows h_offsets[i] ..
+ * h_offsets[i+1]), colours float32 [n_points,3] with NaN -> 0 and
+ * clip(c * 255, 0, 255) / 255 applied on the device.  The destinations may be
+ * device or host buffers (hipMemcpyDefault); returns when they are filled. */
+int pcc_decode_fetch_packed(pcc_codec* codec, int32_t* points, float* colors);
 
 /* ---- capture pre-step ------------------------------- */
 
