@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the 1M-point frame: numpy frames in (as the capturer leaves them), numpy frames out (as
+pack_batches returns them).  bench.py's `value` keeps inputs and outputs resident in HBM; this is the figure a caller
+of the unmodified reference services would see.  Run from the repository root: python tools/bench_pcie.py"""
 import sys, importlib, time, numpy as np, torch
 sys.path.insert(0, '.')
 pkg = importlib.import_module("demo-learned-point-cloud-compression_amd")
