@@ -380,22 +380,6 @@ int rows_to_tensor(pcc_codec* cd, const View& v, const float* rows, int c, float
 }
 
 // SparseTensor.features_at_coordinates: exact-lattice lookup, zeros where absent
-int features_at(pcc_codec* cd, const Feat& x, const int32_t* qcoords, int64_t m, float** out) {
-  const int64_t cap = std::max<int64_t>(m, 1);
-  CODEC_ALLOC(qkeys, uint64_t, cap);
-  CODEC_ALLOC(flag, int32_t, 1);
-  CODEC_ALLOC(rows, int32_t, cap);
-  CODEC_ALLOC(o, float, cap * x.c);
-  if (m > 0) {
-    PCC_HIP(hipMemsetAsync(flag, 0, 4, cd->ctx->stream));
-    PCC_TRY(pcc_morton_keys(cd->ctx, qcoords, m, qkeys, flag));
-    PCC_TRY(pcc_lookup(cd->ctx, x.cs->keys, x.cs->n, qkeys, m, rows));
-    PCC_TRY(pcc_gather_rows_or_zero(cd->ctx, x.f, rows, m, x.c, o));
-  }
-  *out = o;
-  return PCC_OK;
-}
-
 // scale_nn(q) + eps on the host in float32 with the operation order of model.py ScaleNN
 int scale_row(pcc_codec* cd, double qg, double qa, float* out /*[c_y]*/) {
   const Tensor *w0 = find(cd, "scale_nn.l0.weight"), *b0 = find(cd, "scale_nn.l0.bias");
@@ -425,11 +409,41 @@ int scale_row(pcc_codec* cd, double qg, double qa, float* out /*[c_y]*/) {
   return PCC_OK;
 }
 
-int h_s(pcc_codec* cd, const Feat& z_hat, Feat* gp) {
-  Feat a, b;
+// h_s up to its output layer: the 64 generated descendants of every z voxel at stride 8 with their features
+int h_s_up(pcc_codec* cd, const Feat& z_hat, Feat* pre) {
+  Feat a;
   PCC_TRY(up2(cd, "h_s.up0", z_hat, 1, &a));
-  PCC_TRY(up2(cd, "h_s.up1", a, 1, &b));
-  return conv3(cd, "h_s.conv0", b, 0, gp);
+  return up2(cd, "h_s.up1", a, 1, pre);
+}
+
+// h_s output layer + features_at_coordinates(qcoords) in one: the reference evaluates the 32 -> 64 conv on every
+// descendant (4x the latent's rows) and then samples it at the latent's coordinates; a row's value depends only on its
+// own neighbour list, so the conv is run on the sampled rows alone (their rule-book columns), absent rows -> 0.
+int h_s_out_at(pcc_codec* cd, const Feat& pre, const int32_t* qcoords, int64_t m, float** out) {
+  const float *w, *b;
+  const Tensor* tw;
+  PCC_TRY(wb(cd, "h_s.conv0", &w, &b, &tw));
+  const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
+  const int64_t cap = std::max<int64_t>(m, 1);
+  CODEC_ALLOC(qkeys, uint64_t, cap);
+  CODEC_ALLOC(flag, int32_t, 1);
+  CODEC_ALLOC(rows, int32_t, cap);
+  CODEC_ALLOC(self, int32_t, cap);
+  CODEC_ALLOC(nbr_sub, int32_t, 27 * cap);
+  CODEC_ALLOC(conv_o, float, cap * cout);
+  CODEC_ALLOC(o, float, cap * cout);
+  if (m > 0) {
+    int32_t* nbr;
+    PCC_TRY(nbr27_of(cd, pre.cs, &nbr));
+    PCC_HIP(hipMemsetAsync(flag, 0, 4, cd->ctx->stream));
+    PCC_TRY(pcc_morton_keys(cd->ctx, qcoords, m, qkeys, flag));
+    PCC_TRY(pcc_lookup(cd->ctx, pre.cs->keys, pre.cs->n, qkeys, m, rows));
+    PCC_TRY(pcc_gather_map_columns(cd->ctx, nbr, 27, pre.cs->n, rows, m, nbr_sub, self));
+    PCC_TRY(pcc_sparse_conv(cd->ctx, pre.f, pre.cs->n, nbr_sub, 27, m, m, w, b, cin, cout, 0, conv_o));
+    PCC_TRY(pcc_gather_rows_or_zero(cd->ctx, conv_o, self, m, cout, o));
+  }
+  *out = o;
+  return PCC_OK;
 }
 
 // ---------------------------------------------------------------- geometry slot (utils.py)
@@ -873,7 +887,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   // ---- step 4: hyper synthesis h_s -> (scales_hat | means_hat) at stride 8
   t0 = now_s();
   Feat gp;
-  PCC_TRY(h_s(cd, z_hat, &gp));
+  PCC_TRY(h_s_up(cd, z_hat, &gp));
   ts[3] = now_s() - t0;
 
   // ---- step 5: all Q quality streams at once (codec_pipeline.py:397-437)
@@ -881,7 +895,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);
   {
     float* params;
-    PCC_TRY(features_at(cd, gp, yv.coords, ny, &params));
+    PCC_TRY(h_s_out_at(cd, gp, yv.coords, ny, &params));
     std::vector<float> scale_h((size_t)n_q * cy);
     for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &scale_h[(size_t)q * cy]));
     CODEC_ALLOC(scale_d, float, n_q * cy);
@@ -1204,7 +1218,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   // ---- step 4: hyper synthesis
   t0 = now_s();
   Feat gp;
-  PCC_TRY(h_s(cd, z_hat, &gp));
+  PCC_TRY(h_s_up(cd, z_hat, &gp));
   ts[3] = now_s() - t0;
 
   // ---- step 5: decode y, de-quantise with offsets (codec_parallel.py:382-419)
@@ -1214,7 +1228,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     View yv;
     PCC_TRY(view_of(cd, ycs, &yv));
     float* params;
-    PCC_TRY(features_at(cd, gp, yv.coords, ny, &params));
+    PCC_TRY(h_s_out_at(cd, gp, yv.coords, ny, &params));
     std::vector<float> scale_h((size_t)cy);
     PCC_TRY(scale_row(cd, qg, qa, scale_h.data()));
     CODEC_ALLOC(scale_d, float, cy);

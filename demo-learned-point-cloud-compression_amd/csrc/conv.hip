@@ -479,6 +479,12 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32 && compact_rows() != 0 &&
       (uintptr_t)d_out % 16 == 0) {
     launch_compact<false>(st, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);
+  } else if (!force_scalar() && !simple && aligned && cin == 32 && cout == 64 && compact_rows() != 0 &&
+             conv_halfw(n_out) && (uintptr_t)d_out % 16 == 0) {
+    // a 32 -> 64 layer of at most 64k rows (h_s output layer at the latent's rows): 32-row windows, the two column
+    // halves side by side as grid.y
+    hipLaunchKernelGGL((k_gconv_mfma_compact<1, false, false, true, 64>), dim3((nblk(n_out, 32) + 7) / 8 * 8, 2),
+                       dim3(64), 0, st, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);
   } else if (!force_scalar() && !simple && aligned && cin == 32 && cout == 32) {
     hipLaunchKernelGGL((k_gconv_mfma_pipe<1, false>), dim3(gm), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr,
                        k_vol, nbr_pitch, n_out, d_w, d_bias, relu, d_out, nof, nof, nofo);

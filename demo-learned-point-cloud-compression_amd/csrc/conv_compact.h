@@ -48,13 +48,18 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // the 27 x 8N child rule book is never written to or read from HBM.
 // HALFW: 32-row windows (lanes 32..63 own no row): every offset is ONE group, so a window's 27 dependent steps are
 // shorter — for launches of a single round of windows, whose duration is one window's latency, not throughput.
-template <int RCH, bool HEAD, bool UP = false, bool HALFW = false>
+// COUT: output channels of the layer (32 or 64).  A workgroup always produces 32 of them, columns [32 blockIdx.y,
+// 32 blockIdx.y + 32): a 32 -> 64 layer launches grid.y = 2 and the two halves of a window run side by side (used for
+// the h_s output layer evaluated at the latent's rows only — a launch far smaller than one round of windows).
+template <int RCH, bool HEAD, bool UP = false, bool HALFW = false, int COUT = 32>
 __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
     float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
     float* __restrict__ head_out) {
   static_assert(!HALFW || RCH == 1, "half windows are a variant of the 64-row kernel");
+  static_assert(COUT == 32 || (COUT == 64 && !HEAD), "the fused head reads all channels of a row");
+  const int col0 = COUT == 32 ? 0 : 32 * (int)blockIdx.y;
   constexpr int R = HALFW ? 32 : 64 * RCH;  // output rows of this wave
   constexpr int AP = 36;       // accumulator row pitch (floats), 16-B aligned rows
   __shared__ __attribute__((aligned(16))) float acc_lds[(R + 1) * AP];  // row R = sink for pad slots
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
 
   // ---- accumulators start at the bias
   {
-    const float4 b4 = make_float4(bias[chunk * 4], bias[chunk * 4 + 1], bias[chunk * 4 + 2], bias[chunk * 4 + 3]);
+    const float* bp = bias + col0 + chunk * 4;
+    const float4 b4 = make_float4(bp[0], bp[1], bp[2], bp[3]);
 #pragma unroll
     for (int it = 0; it < R / 8; ++it)
       *reinterpret_cast<float4*>(&acc_lds[(it * 8 + grow) * AP + chunk * 4]) = b4;
@@ -133,9 +139,9 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
   float4 gA[NG][4], gB[NG][4];
   float bw[16];
   auto load_w = [&](int k) {
-    const float* wk = w + (int64_t)k * 32 * 32;
+    const float* wk = w + (int64_t)k * 32 * COUT + col0;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) bw[s] = wk[(2 * s + h) * 32 + i];
+    for (int s = 0; s < 16; ++s) bw[s] = wk[(2 * s + h) * COUT + i];
   };
 
 #define PCC_WAVE_SYNC()                                      \
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
+    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * COUT + col0 + chunk * 4) = v;
   }
   if constexpr (HEAD) {
 #pragma unroll

@@ -249,6 +249,30 @@ extern "C" int pcc_derive_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent, int6
   return PCC_OK;
 }
 
+// rule book of a subset of a level's rows: out[k][j] = nbr[k][rows[j]] (or -1 where rows[j] < 0)
+__global__ __launch_bounds__(256) void k_gather_map_columns(const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+                                                            const int32_t* __restrict__ rows, int64_t m,
+                                                            int32_t* __restrict__ out, int32_t* __restrict__ self) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int32_t r = rows[j];
+  for (int k = 0; k < k_vol; ++k) out[(int64_t)k * m + j] = r >= 0 ? nbr[(int64_t)k * pitch + r] : -1;
+  if (self) self[j] = r >= 0 ? (int32_t)j : -1;
+}
+
+extern "C" int pcc_gather_map_columns(pcc_ctx* ctx, const int32_t* d_nbr, int k_vol, int64_t pitch,
+                                      const int32_t* d_rows, int64_t m, int32_t* d_nbr_out, int32_t* d_self) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_gather_map_columns: null ctx");
+  if (m <= 0) return PCC_OK;
+  PCC_REQUIRE(d_nbr && d_rows && d_nbr_out && k_vol >= 1 && k_vol <= 27 && pitch >= 1, PCC_E_ARG,
+              "pcc_gather_map_columns: bad buffers");
+  PccProfScope prof(ctx, "gather_map_columns", m, k_vol, 0, 0);
+  hipLaunchKernelGGL(k_gather_map_columns, dim3(nblk(m, 256)), dim3(256), 0, ctx->stream, d_nbr, k_vol, pitch, d_rows,
+                     m, d_nbr_out, d_self);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 extern "C" int pcc_subset_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t parent_pitch,
                                  const uint32_t* d_keep, const int32_t* d_remap, int64_t n_keep, int32_t* d_nbr) {
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_subset_map_up: null ctx");

@@ -261,6 +261,16 @@ class Runtime:
                                          n_keep, _ptr(nbr)), "pcc_subset_map_up")
         return nbr
 
+    def gather_map_columns(self, nbr, rows):
+        """(rule book [K, m] of the subset rows `rows` (int32, -1 = absent) of a level with book nbr [K, n],
+        self [m] = j where rows[j] >= 0 else -1)"""
+        k_vol, m = nbr.shape[0], rows.shape[0]
+        out = self.empty((k_vol, m), torch.int32)
+        me = self.empty((m,), torch.int32)
+        check(self.lib.pcc_gather_map_columns(self.ctx, _ptr(nbr), k_vol, nbr.stride(0), _ptr(rows), m, _ptr(out),
+                                              _ptr(me)), "pcc_gather_map_columns")
+        return out, me
+
     def derive_map_down(self, nbr_parent, nbr8, parent_of, keys, child_shift):
         n = keys.shape[0]
         nbr = self.empty((27, n), torch.int32)

@@ -245,6 +245,17 @@ int pcc_subset_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent,
                       int64_t parent_pitch, const uint32_t* d_keep,
                       const int32_t* d_remap, int64_t n_keep, int32_t* d_nbr);
 
+/* rule book of a SUBSET of the output rows of a layer: d_nbr_out[k][j] =
+ * d_nbr[k][d_rows[j]], or -1 where d_rows[j] < 0 ([k_vol, m], pitch m);
+ * d_self (nullable) [m] = j where d_rows[j] >= 0, else -1.  With it a conv whose
+ * output is only sampled afterwards (h_s followed by features_at_coordinates at
+ * the latent's coordinates, codec_pipeline.py:401 / codec_parallel.py:387) is
+ * evaluated at the sampled rows alone: same bits per row, a quarter of the rows;
+ * pcc_gather_rows_or_zero(out, d_self) then zeroes the rows that were absent. */
+int pcc_gather_map_columns(pcc_ctx* ctx, const int32_t* d_nbr, int k_vol,
+                           int64_t pitch, const int32_t* d_rows, int64_t m,
+                           int32_t* d_nbr_out, int32_t* d_self);
+
 /* replaces: MinkowskiGenerativeConvolutionTranspose forward (kernel 2,
  * stride 2): out[8p+o] = W[o]^T in[p] + bias. */
 int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in,

@@ -428,6 +428,29 @@ def test_conv_head_up_refuses_when_family_is_off(rt):
         assert want in out.stdout, (env, out.stdout, out.stderr[-400:])
 
 
+@pytest.mark.parametrize("cout", [32, 64])
+@pytest.mark.parametrize("n,m", [(5000, 1300), (40, 40), (3000, 1)])
+def test_conv_on_a_subset_of_the_rows(rt, oracle, cout, n, m):
+    """a conv whose output is only sampled afterwards, evaluated at the sampled rows alone (pcc_gather_map_columns +
+    pcc_sparse_conv with n_out != n_in): the same bits as the rows of the full conv, absent rows (-1) zeroed by
+    pcc_gather_rows_or_zero — the native codec's form of h_s + features_at_coordinates"""
+    rng = np.random.default_rng(n + cout)
+    keys = sorted_keys(oracle, _structured_cloud("children", n))
+    n = len(keys)
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(n, 32)).astype(np.float32)
+    w, b = _weights(rng, 27, 32, cout)
+    full = oracle.sparse_conv(x, nbr, w, b, False)
+    rows = rng.choice(n, size=min(m, n), replace=False).astype(np.int32)
+    rows[::5] = -1                                         # coordinates that are not in the set
+    sub, me = rt.gather_map_columns(dev(rt, nbr), dev(rt, rows))
+    assert np.array_equal(host(sub), np.where(rows[None, :] >= 0, nbr[:, np.maximum(rows, 0)], -1))
+    out = rt.sparse_conv(dev(rt, x), sub, dev(rt, w), dev(rt, b), False)
+    got = host(rt.gather_rows_or_zero(out, me))
+    ref = np.where(rows[:, None] >= 0, full[np.maximum(rows, 0)], 0).astype(np.float32)
+    assert np.array_equal(got, ref)
+
+
 def test_conv_ops_on_the_shared_weight_kernel():
     """layers of >= 200k rows run four windows per workgroup with the weights shared through LDS; the op tests above
     are far smaller, so they are run once more in a child process with PCC_CONV_W4=1 (that kernel for every size:
