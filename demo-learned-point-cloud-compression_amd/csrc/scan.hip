@@ -1,8 +1,9 @@
 // scan.hip — device-wide exclusive prefix sum (uint32), reduce-then-scan.
 //
 // Used by every compaction on the path (parent-coordinate dedup, top-k prune,
-// radix-sort digit offsets, octree level build).  Three launches per level of
-// recursion; the tile is 2048 elements (256 threads x 8, two dwordx4 loads per
+// radix-sort digit offsets, octree level build).  Two launches up to 4M elements
+// (block sums, then every block adds up the sums before its own and scans its
+// tile), three per level of recursion above; the tile is 2048 elements (256 threads x 8, two dwordx4 loads per
 // lane), wave64 shuffles for the in-wave part, one LDS exchange per block.
 //
 // Tried and dropped: one launch per scan with the tiles chained by decoupled
@@ -66,6 +67,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(
 }
 
 // in/out may alias (in-place scan): no __restrict__ on them.
+// block_offs: exclusive offsets of the tiles (scanned block sums), or — SUMS_RAW — the raw block sums themselves:
+// the block then adds up the sums of the tiles before its own (<= 2048 values) instead of a middle launch doing it.
+template <bool SUMS_RAW>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(
     const uint32_t* in, uint32_t* out, int64_t n,
     const uint32_t* __restrict__ block_offs /*nullable*/,
@@ -82,12 +86,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = (base + i < n) ? in[base + i] : 0u;
   }
+  uint32_t tile_off = 0;
+  if constexpr (SUMS_RAW) {
+    uint32_t part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) part += block_offs[i];
+    block_excl_scan(part, &tile_off, lds);
+  } else {
+    tile_off = block_offs ? block_offs[blockIdx.x] : 0u;
+  }
   uint32_t s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
   uint32_t tot;
   uint32_t ex = block_excl_scan(s, &tot, lds);
-  ex += block_offs ? block_offs[blockIdx.x] : 0u;
+  ex += tile_off;
   uint32_t o[SCAN_ITEMS];
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) { o[i] = ex; ex += v[i]; }
@@ -123,7 +135,7 @@ int pcc_scan_exclusive_u32(pcc_ctx* ctx, const uint32_t* d_in, uint32_t* d_out,
   }
   const int64_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nblk == 1) {
-    hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream,
+    hipLaunchKernelGGL((k_scan_apply<false>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream,
                        d_in, d_out, n, (const uint32_t*)nullptr, d_total);
     PCC_CHECK_LAUNCH();
     return PCC_OK;
@@ -133,8 +145,15 @@ int pcc_scan_exclusive_u32(pcc_ctx* ctx, const uint32_t* d_in, uint32_t* d_out,
   hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblk), dim3(SCAN_THREADS), 0,
                      ctx->stream, d_in, n, sums);
   PCC_CHECK_LAUNCH();
+  if (nblk <= SCAN_TILE) {
+    // up to 2048 tiles (4M elements): every block sums the tiles before its own — two launches instead of three
+    hipLaunchKernelGGL((k_scan_apply<true>), dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n,
+                       (const uint32_t*)sums, d_total);
+    PCC_CHECK_LAUNCH();
+    return PCC_OK;
+  }
   PCC_TRY(pcc_scan_exclusive_u32(ctx, sums, sums, nblk, nullptr));
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(SCAN_THREADS), 0,
+  hipLaunchKernelGGL((k_scan_apply<false>), dim3((unsigned)nblk), dim3(SCAN_THREADS), 0,
                      ctx->stream, d_in, d_out, n, (const uint32_t*)sums, d_total);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
