@@ -7,9 +7,11 @@
 // codec_parallel.py does exactly that, op by op), so both routes write byte-identical containers
 // and reconstruct identical frames.  What this file adds is the host side in native code: the model
 // graph (DESIGN.md MODEL), coordinate-set bookkeeping, a per-codec device pool instead of a tensor
-// allocator, pinned staging, and the overlap of the serial host coders with the GPU (a helper
-// thread codes the geometry blobs and the z stream while the stream runs h_s and the y symbols; the
-// Q quality streams are coded on Q threads).
+// allocator, pinned staging, and the overlap of the serial host coders with the GPU (encoder: the
+// stream runs analysis, hyper path and quantiser without a host synchronisation; the Q quality
+// streams are then coded on Q threads while this thread produces the geometry slots — their kernels
+// queue up behind the quantiser — and the z string; decoder: a helper thread decodes the z string
+// while the coordinates are rebuilt, and the first synthesis rule book is built during the y decode).
 //
 // Host-only code (no kernels); compiled as HIP source for the runtime API.
 #include "common.h"
@@ -761,14 +763,12 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   if (ny > 0) PCC_TRY(pcc_gather_rows(ctx, y.f, yv.perm, ny, 4 * cy, ys_f));
   const std::vector<int64_t>* yoffs;
   PCC_TRY(offsets_of(cd, y.cs, &yoffs));
-  PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 8));
-  if (ny > 0) PCC_HIP(hipMemcpyAsync(cd->pin_keys.p, y.cs->keys, (size_t)ny * 8, hipMemcpyDeviceToHost, st));
-  PCC_HIP(hipStreamSynchronize(st));
-  const uint64_t* ykeys_h = (const uint64_t*)cd->pin_keys.p;
   ts[0] = now_s() - t0;
 
-  // ---- step 6 (device half): octree occupancy bytes of every frame (codec_pipeline.py:441-462)
-  t0 = now_s();
+  // ---- step 6: geometry slot of every frame (codec_pipeline.py:441-462).  Nothing on the GPU path needs it, so it is
+  // only DEFINED here: it runs on this thread after the y symbols are on their way to the coder threads (below), its
+  // kernels queue up behind the quantiser instead of in front of h_a, and its host half (occupancy coding, z string)
+  // overlaps the y coders.
   struct FrameGeo {
     int64_t n, occ_off, occ_len;
     int depth;
@@ -776,7 +776,13 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     std::vector<int64_t> level_n;
   };
   std::vector<FrameGeo> geo((size_t)n_frames);
-  {
+  double geo_dev_s = 0;
+  auto geometry_device_half = [&]() -> int {
+    const double tg = now_s();
+    PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 8));
+    if (ny > 0) PCC_HIP(hipMemcpyAsync(cd->pin_keys.p, y.cs->keys, (size_t)ny * 8, hipMemcpyDeviceToHost, st));
+    PCC_HIP(hipStreamSynchronize(st));
+    const uint64_t* ykeys_h = (const uint64_t*)cd->pin_keys.p;
     int64_t cap_total = 0;
     for (int f = 0; f < n_frames; ++f) {
       FrameGeo& g = geo[f];
@@ -801,8 +807,10 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       for (int64_t v : g.level_n) g.occ_len += v;
       PCC_HIP(hipMemcpyAsync(cd->pin_occ.p + g.occ_off, occ + g.occ_off, (size_t)g.occ_len, hipMemcpyDeviceToHost, st));
     }
-  }
-  ts[4] = now_s() - t0;
+    PCC_HIP(hipStreamSynchronize(st));  // occupancy bytes and (earlier in the stream) the z symbols are on the host
+    geo_dev_s = now_s() - tg;
+    return PCC_OK;
+  };
 
   // ---- step 2: hyper analysis h_a
   t0 = now_s();
@@ -835,53 +843,34 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_TRY(rows_to_tensor(cd, zv, zhat_rows, cz, &zf));
     z_hat = {z.cs, zf, cz};
   }
-  Event ev_host_own;
-  PCC_REQUIRE(ev_host_own.create() == PCC_OK, PCC_E_HIP, "pcc_encode_gop: hipEventCreate failed");
-  const hipEvent_t ev_host = ev_host_own.e;
-  PCC_HIP(hipEventRecord(ev_host, st));
-  // helper thread: geometry blobs + z string, neither feeds the GPU path
+  // host half of the geometry slot + the z string (codec_pipeline.py:294-317): run by this thread next to the y coders
   std::vector<std::vector<uint8_t>> blobs((size_t)n_frames);
   std::vector<uint8_t> z_string;
-  int helper_rc = PCC_OK;
-  std::string helper_err;
   double helper_geo_s = 0, helper_z_s = 0;
   const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
                *eb_off = find(cd, "entropy_bottleneck.offset");
   PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_encode_gop: entropy_bottleneck tables missing");
-  std::thread helper([&]() {
-    (void)hipSetDevice(cd->device);
-    if (hipEventSynchronize(ev_host) != hipSuccess) {
-      helper_rc = PCC_E_HIP;
-      helper_err = "hipEventSynchronize failed";
-      return;
-    }
+  auto side_streams = [&]() -> int {
+    PCC_TRY(geometry_device_half());
     double t = now_s();
-    for (int f = 0; f < n_frames && helper_rc == PCC_OK; ++f) {
+    for (int f = 0; f < n_frames; ++f) {
       const FrameGeo& g = geo[f];
       const int64_t cap = 64 + 2 * g.occ_len + 16;
       blobs[f].resize((size_t)cap);
       int64_t len = 0;
       const int64_t zero = 0;
-      helper_rc = pcc_octree_pack(g.n ? cd->pin_occ.p + g.occ_off : nullptr, g.n ? g.level_n.data() : &zero, g.depth,
-                                  g.n, g.origin, blobs[f].data(), cap, &len);
-      if (helper_rc == PCC_OK) blobs[f].resize((size_t)len);
+      PCC_TRY(pcc_octree_pack(g.n ? cd->pin_occ.p + g.occ_off : nullptr, g.n ? g.level_n.data() : &zero, g.depth, g.n,
+                              g.origin, blobs[f].data(), cap, &len));
+      blobs[f].resize((size_t)len);
     }
     helper_geo_s = now_s() - t;
     t = now_s();
-    if (helper_rc == PCC_OK) {
-      std::vector<int32_t> idx((size_t)nz * cz);
-      for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz, idx.begin() + (size_t)(c + 1) * nz, c);
-      helper_rc = rans_encode_grow((const int32_t*)cd->pin_zsym.p, idx.data(), nz * cz, eb_cdf, eb_len, eb_off, &z_string);
-    }
+    std::vector<int32_t> idx((size_t)nz * cz);
+    for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz, idx.begin() + (size_t)(c + 1) * nz, c);
+    PCC_TRY(rans_encode_grow((const int32_t*)cd->pin_zsym.p, idx.data(), nz * cz, eb_cdf, eb_len, eb_off, &z_string));
     helper_z_s = now_s() - t;
-    if (helper_rc != PCC_OK) helper_err = pcc_last_error();
-  });
-  struct Joiner {  // the helper references locals: never leave this frame with it running
-    std::thread& t;
-    ~Joiner() {
-      if (t.joinable()) t.join();
-    }
-  } joiner{helper};
+    return PCC_OK;
+  };
   ts[2] = now_s() - t0;
 
   // ---- step 4: hyper synthesis h_s -> (scales_hat | means_hat) at stride 8
@@ -947,6 +936,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     int64_t cap = 2 * per + 4096;
     std::vector<int> rcq((size_t)n_q, PCC_OK);
     std::vector<std::string> errq((size_t)n_q);
+    int side_rc = PCC_OK;
     auto code_quality = [&](int q) {
       (void)hipSetDevice(cd->device);
       GateUser gu{evc.data(), false};
@@ -991,9 +981,10 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         }
       } pool;
       pool.th.reserve((size_t)n_q);
-      for (int q = 1; q < n_q; ++q) pool.th.emplace_back(code_quality, q);
-      code_quality(0);
+      for (int q = 0; q < n_q; ++q) pool.th.emplace_back(code_quality, q);
+      side_rc = side_streams();  // geometry slots + z string on this thread meanwhile (joins on scope exit)
     }
+    PCC_TRY(side_rc);
     for (int q = 0; q < n_q; ++q)
       if (rcq[q] != PCC_OK) {
         pcc_set_error("pcc_encode_gop (y stream %d): %s", q, errq[q].c_str());
@@ -1024,12 +1015,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   }
   ts[5] = now_s() - t0;
 
-  helper.join();
-  if (helper_rc != PCC_OK) {
-    pcc_set_error("pcc_encode_gop (host coders): %s", helper_err.c_str());
-    return helper_rc;
-  }
-  ts[4] += helper_geo_s;
+  ts[4] = geo_dev_s + helper_geo_s;  // these two ran next to the y coders, inside the gaussian stage's wall time
   ts[2] += helper_z_s;
 
   // ---- step 7: containers, field for field the reference writer (codec_pipeline.py:464-517)
