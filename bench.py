@@ -259,6 +259,14 @@ def main():
                 roofline["traffic_source"] = "profiles/pmc_latest.json: (2*FETCH_SIZE+WRITE_SIZE)*1024"
         except (OSError, KeyError, ValueError):
             pass
+        # the other roof, for the record: the same launch priced against the one that does NOT bind it
+        roofline["other_roof"] = ({"bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "min_ms": 1e3 * t_hbm}
+                                  if roofline["bound"] == "mfma" else
+                                  {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                   "min_ms": 1e3 * t_mfma})
+        roofline["min_ms"] = 1e3 * max(t_hbm, t_mfma)
         roofline.update({"kernel": f"{op}{list(dims)}", "avg_ms": avg_s * 1e3, "launches": cnt,
                          "algorithmic_bytes": nbytes, "algorithmic_flops": flops, "active_pairs": p})
 
