@@ -7,8 +7,10 @@
 // the order-preserving integer image of the logit (4 histogram passes), ties at
 // the threshold are resolved by row order (lower Morton key first); one prefix
 // scan over the "above" and "equal" flags ranks both and places the survivors
-// (stable compaction).  14 launches per call (was 20): at the sizes of this path
-// a call is launch-bound, not bandwidth-bound.
+// (stable compaction).  9 launches per call (was 20: every block now advances the
+// threshold state itself from the finished histograms instead of a one-block
+// update launch per pass): at the sizes of this path a call is launch-bound, not
+// bandwidth-bound.
 // No sort of the 2M candidates, no floating-point comparisons that could
 // differ between encoder, decoder and the CPU oracle.
 #include "common.h"
@@ -28,6 +30,45 @@ __device__ __forceinline__ uint32_t ordered_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// The threshold after `passes` histogram passes, recomputed by every block for itself from the initial state and the
+// finished histograms (hist layout [pass][frame][256]): for each pass the digit d with
+//   (keys above d among the candidates) < k_rem <= (those + keys with digit d),
+// walking from the top digit down and stopping at d = 0 — k_topk_update's serial walk as a 256-lane suffix sum.
+// 256 threads; a few hundred cycles per pass, against one launch per pass saved.
+__device__ __forceinline__ TopkState topk_state_after(TopkState s, const uint32_t* __restrict__ hist, int n_frames,
+                                                      int f, int passes, uint32_t* lds /*[8]*/) {
+  if (s.mode != 2) return s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int p = 0; p < passes; ++p) {
+    const uint32_t c = hist[((size_t)p * n_frames + f) * 256 + (255 - t)];  // thread t holds digit 255 - t
+    uint32_t inc = c;  // inclusive prefix over descending digits = keys with digit >= 255 - t
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += u;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    inc += base;
+    const uint32_t above = inc - c;  // keys with a larger digit
+    const int digit = 255 - t;
+    // the walk stops at the first digit (from the top) whose cumulative count reaches k_rem, but not below digit 1
+    const bool hit = digit >= 1 && above < s.k_rem && s.k_rem <= inc;
+    if (hit) { lds[4] = (uint32_t)digit; lds[5] = above; }
+    if (t == 255) { lds[6] = above; }  // digit 0: everything above it
+    __syncthreads();
+    // exactly one digit >= 1 hits unless the candidates above digit 0 are fewer than k_rem
+    const bool any = lds[6] >= s.k_rem;  // the cumulative count reaches k_rem at some digit >= 1
+    const uint32_t dsel = any ? lds[4] : 0u, rem_sub = any ? lds[5] : lds[6];
+    s.prefix |= dsel << (24 - 8 * p);
+    s.k_rem -= rem_sub;
+    __syncthreads();
+  }
+  return s;
+}
+
 // grid (gx, F): histogram of the current digit over keys of frame f matching the prefix.  Pass 0 reads the logits
 // and leaves their order-preserving integer images in `keys` for the later passes.
 // (Closing a pass in the same launch — the last block of a frame to take a ticket walks the histogram — was
@@ -35,13 +76,14 @@ __device__ __forceinline__ uint32_t ordered_key(float v) {
 // freshly written keys in pass 0: 64-97 us per pass instead of 5-23.)
 __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ logits, uint32_t* __restrict__ keys,
                                                    const int64_t* __restrict__ offs,
-                                                   const TopkState* __restrict__ state, int pass,
-                                                   uint32_t* __restrict__ hist) {
+                                                   const TopkState* __restrict__ state0, int pass,
+                                                   uint32_t* __restrict__ hist, int n_frames) {
   __shared__ uint32_t lh[256];
+  __shared__ uint32_t st_lds[8];
   const int f = blockIdx.y;
-  const TopkState s = state[f];
   const int64_t lo = offs[f], hi = offs[f + 1];
-  if (s.mode != 2) return;  // nothing to select in this frame: its keys are never read
+  if (state0[f].mode != 2) return;  // nothing to select in this frame: its keys are never read (block-uniform)
+  const TopkState s = topk_state_after(state0[f], hist, n_frames, f, pass, st_lds);
   lh[threadIdx.x] = 0;
   __syncthreads();
   const int shift = 24 - 8 * pass;
@@ -58,30 +100,7 @@ __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ log
   }
   __syncthreads();
   const uint32_t c = lh[threadIdx.x];
-  if (c) atomicAdd(&hist[f * 256 + threadIdx.x], c);
-}
-
-// one block per frame: walk the histogram from the top digit down, then clear it for the next pass
-__global__ void k_topk_update(uint32_t* __restrict__ hist, TopkState* __restrict__ state, int pass) {
-  const int f = blockIdx.x;
-  if (threadIdx.x == 0) {
-    TopkState s = state[f];
-    if (s.mode == 2) {
-      const int shift = 24 - 8 * pass;
-      uint32_t rem = s.k_rem;
-      int d = 255;
-      for (; d > 0; --d) {
-        const uint32_t c = hist[f * 256 + d];
-        if (c >= rem) break;
-        rem -= c;
-      }
-      s.prefix |= (uint32_t)d << shift;
-      s.k_rem = rem;
-      state[f] = s;
-    }
-  }
-  __syncthreads();
-  for (int d = threadIdx.x; d < 256; d += blockDim.x) hist[f * 256 + d] = 0;
+  if (c) atomicAdd(&hist[((size_t)pass * n_frames + f) * 256 + threadIdx.x], c);
 }
 
 // keep = every key above the threshold + the first k_rem keys equal to it in row order.  One flag array of 2n
@@ -89,10 +108,12 @@ __global__ void k_topk_update(uint32_t* __restrict__ hist, TopkState* __restrict
 // first, and only differences within a frame are used).
 __global__ __launch_bounds__(256) void k_topk_flags(const uint32_t* __restrict__ keys,
                                                     const int64_t* __restrict__ offs,
-                                                    const TopkState* __restrict__ state, int64_t n,
+                                                    const TopkState* __restrict__ state0,
+                                                    const uint32_t* __restrict__ hist, int n_frames, int64_t n,
                                                     uint32_t* __restrict__ fl) {
+  __shared__ uint32_t st_lds[8];
   const int f = blockIdx.y;
-  const TopkState s = state[f];
+  const TopkState s = topk_state_after(state0[f], hist, n_frames, f, 4, st_lds);
   const int64_t lo = offs[f], hi = offs[f + 1];
   for (int64_t r = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; r < hi; r += (int64_t)gridDim.x * 256) {
     uint32_t gt = 0u, eq = 0u;
@@ -110,10 +131,12 @@ __global__ __launch_bounds__(256) void k_topk_flags(const uint32_t* __restrict__
 
 __global__ __launch_bounds__(256) void k_topk_emit(const uint32_t* __restrict__ fl, const uint32_t* __restrict__ ex,
                                                    const int64_t* __restrict__ offs,
-                                                   const TopkState* __restrict__ state, int64_t n,
+                                                   const TopkState* __restrict__ state0,
+                                                   const uint32_t* __restrict__ hist, int n_frames, int64_t n,
                                                    uint32_t* __restrict__ rows) {
+  __shared__ uint32_t st_lds[8];
   const int f = blockIdx.y;
-  const TopkState s = state[f];
+  const TopkState s = topk_state_after(state0[f], hist, n_frames, f, 4, st_lds);
   const int64_t lo = offs[f], hi = offs[f + 1];
   if (lo >= hi) return;
   const uint32_t gt_base = ex[lo], eq_base = ex[n + lo];
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(256) void k_topk_params(TopkArgs a, int n_batch, in
   const int t = threadIdx.x;
   if (t <= n_batch) offs[t] = a.offs[t];
   if (t < n_batch) state[t] = a.st[t];
-  for (int j = t; j < 256 * n_batch; j += 256) hist[j] = 0u;
+  for (int j = t; j < 4 * 256 * n_batch; j += 256) hist[j] = 0u;  // one histogram per pass
 }
 
 extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, int n_batch,
@@ -153,12 +176,12 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
               "pcc_topk_prune: offsets must span [0,n]");
   hipStream_t st = ctx->stream;
   const size_t nb4 = pcc_align((size_t)n * 4);
-  PCC_TRY(pcc_arena_reserve(ctx, 5 * nb4 + pcc_scan_scratch_bytes(2 * n) + 256 * 4 * (size_t)n_batch + 8192 +
+  PCC_TRY(pcc_arena_reserve(ctx, 5 * nb4 + pcc_scan_scratch_bytes(2 * n) + 4 * 256 * 4 * (size_t)n_batch + 8192 +
                                      (size_t)n_batch * 64));
   uint32_t* keys = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
   uint32_t* fl = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 8);    // "above" flags, then "equal" flags
   uint32_t* ex = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 8);    // their exclusive scan
-  uint32_t* hist = (uint32_t*)pcc_arena_alloc(ctx, (size_t)256 * 4 * n_batch);
+  uint32_t* hist = (uint32_t*)pcc_arena_alloc(ctx, (size_t)4 * 256 * 4 * n_batch);  // [pass][frame][256]
   int64_t* offs = (int64_t*)pcc_arena_alloc(ctx, (size_t)(n_batch + 1) * 8);
   TopkState* state = (TopkState*)pcc_arena_alloc(ctx, sizeof(TopkState) * n_batch);
   if (!keys || !fl || !ex || !hist || !offs || !state) return PCC_E_NOMEM;
@@ -189,7 +212,7 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
   } else {
     PCC_HIP(hipMemcpyAsync(offs, hp, (size_t)(n_batch + 1) * 8, hipMemcpyHostToDevice, st));
     PCC_HIP(hipMemcpyAsync(state, hs, sizeof(TopkState) * n_batch, hipMemcpyHostToDevice, st));
-    PCC_HIP(hipMemsetAsync(hist, 0, (size_t)256 * 4 * n_batch, st));
+    PCC_HIP(hipMemsetAsync(hist, 0, (size_t)4 * 256 * 4 * n_batch, st));
   }
   // the pinned buffer is reused below only after the final synchronise
 
@@ -199,17 +222,15 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
   const dim3 grid2(gx, (unsigned)n_batch);
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(k_topk_hist, grid2, dim3(256), 0, st, d_logits, keys, (const int64_t*)offs,
-                       (const TopkState*)state, pass, hist);
-    PCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_topk_update, dim3((unsigned)n_batch), dim3(64), 0, st, hist, state, pass);
+                       (const TopkState*)state, pass, hist, n_batch);
     PCC_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_topk_flags, grid2, dim3(256), 0, st, (const uint32_t*)keys, (const int64_t*)offs,
-                     (const TopkState*)state, n, fl);
+                     (const TopkState*)state, (const uint32_t*)hist, n_batch, n, fl);
   PCC_CHECK_LAUNCH();
   PCC_TRY(pcc_scan_exclusive_u32(ctx, fl, ex, 2 * n, nullptr));
   hipLaunchKernelGGL(k_topk_emit, grid2, dim3(256), 0, st, (const uint32_t*)fl, (const uint32_t*)ex,
-                     (const int64_t*)offs, (const TopkState*)state, n, d_keep_rows);
+                     (const int64_t*)offs, (const TopkState*)state, (const uint32_t*)hist, n_batch, n, d_keep_rows);
   PCC_CHECK_LAUNCH();
   // the number of kept rows is sum_f min(k_f, cnt_f) by construction (exact top-k, ties broken by row): no read-back
   if (h_n_keep) *h_n_keep = kept;
