@@ -107,6 +107,7 @@ PROTOTYPES = {
     "pcc_octree_pack": (i32, [vp, pi64, i32, i64, pi32, vp, i64, pi64]),
     "pcc_octree_peek": (i32, [vp, i64, pi64, pi32, pi32]),
     "pcc_octree_unpack": (i32, [vp, i64, vp, i64]),
+    "pcc_octree_unpack_levels": (i32, [vp, i64, vp, i64, pi64]),
     "pcc_vox_valid": (i32, [vp, vp, i64, f32, vp, pf32, pi64]),
     "pcc_vox_keys": (i32, [vp, vp, vp, i64, C.POINTER(C.c_double), C.c_double, vp, vp]),
     "pcc_vox_mean": (i32, [vp, vp, vp, vp, i64, C.c_double, vp, vp, i64, pi64]),

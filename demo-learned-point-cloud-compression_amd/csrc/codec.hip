@@ -381,7 +381,6 @@ int rows_to_tensor(pcc_codec* cd, const View& v, const float* rows, int c, float
   return PCC_OK;
 }
 
-// SparseTensor.features_at_coordinates: exact-lattice lookup, zeros where absent
 // scale_nn(q) + eps on the host in float32 with the operation order of model.py ScaleNN
 int scale_row(pcc_codec* cd, double qg, double qa, float* out /*[c_y]*/) {
   const Tensor *w0 = find(cd, "scale_nn.l0.weight"), *b0 = find(cd, "scale_nn.l0.bias");
@@ -411,6 +410,22 @@ int scale_row(pcc_codec* cd, double qg, double qa, float* out /*[c_y]*/) {
   return PCC_OK;
 }
 
+// Row of every latent voxel among the 64 generated descendants of its stride-32 ancestor: the descendants are laid
+// out as row = (8 z_row + octant at stride 16) * 8 + octant at stride 8, and the two stride-2 coordinate maps that
+// produced z from y hold the ancestors — no hash table, no lookup.  j runs over the latent's canonical order.
+__global__ __launch_bounds__(256) void k_descendant_rows(const uint32_t* __restrict__ perm,
+                                                         const uint64_t* __restrict__ ykeys,
+                                                         const int32_t* __restrict__ parent_of8,
+                                                         const int32_t* __restrict__ parent_of16, int64_t m,
+                                                         int32_t* __restrict__ rows) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t r = perm[j];
+  const uint64_t k = ykeys[r];
+  const int32_t p32 = parent_of16[parent_of8[r]];
+  rows[j] = (int32_t)((((int64_t)p32 * 8 + (int64_t)((k >> 12) & 7ull)) * 8) + (int64_t)((k >> 9) & 7ull));
+}
+
 // h_s up to its output layer: the 64 generated descendants of every z voxel at stride 8 with their features
 int h_s_up(pcc_codec* cd, const Feat& z_hat, Feat* pre) {
   Feat a;
@@ -421,7 +436,9 @@ int h_s_up(pcc_codec* cd, const Feat& z_hat, Feat* pre) {
 // h_s output layer + features_at_coordinates(qcoords) in one: the reference evaluates the 32 -> 64 conv on every
 // descendant (4x the latent's rows) and then samples it at the latent's coordinates; a row's value depends only on its
 // own neighbour list, so the conv is run on the sampled rows alone (their rule-book columns), absent rows -> 0.
-int h_s_out_at(pcc_codec* cd, const Feat& pre, const int32_t* qcoords, int64_t m, float** out) {
+int h_s_out_at(pcc_codec* cd, const Feat& pre, const CS* ycs, const View& yv, float** out) {
+  const int32_t* qcoords = yv.coords;
+  const int64_t m = yv.n;
   const float *w, *b;
   const Tensor* tw;
   PCC_TRY(wb(cd, "h_s.conv0", &w, &b, &tw));
@@ -437,9 +454,20 @@ int h_s_out_at(pcc_codec* cd, const Feat& pre, const int32_t* qcoords, int64_t m
   if (m > 0) {
     int32_t* nbr;
     PCC_TRY(nbr27_of(cd, pre.cs, &nbr));
-    PCC_HIP(hipMemsetAsync(flag, 0, 4, cd->ctx->stream));
-    PCC_TRY(pcc_morton_keys(cd->ctx, qcoords, m, qkeys, flag));
-    PCC_TRY(pcc_lookup(cd->ctx, pre.cs->keys, pre.cs->n, qkeys, m, rows));
+    const CS* z16 = ycs->down;
+    const CS* z32 = z16 ? z16->down : nullptr;
+    const bool by_structure = ycs->stride == 8 && ycs->n == m && z32 && ycs->parent_of && z16->parent_of &&
+                              pre.cs->gen_parent && pre.cs->gen_parent->gen_parent == z32;
+    if (by_structure) {  // pre = up(up(z)) and z = down(down(y)): the rows follow from the two parent maps
+      hipLaunchKernelGGL(k_descendant_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, cd->ctx->stream,
+                         (const uint32_t*)yv.perm, (const uint64_t*)ycs->keys, (const int32_t*)ycs->parent_of,
+                         (const int32_t*)z16->parent_of, m, rows);
+      PCC_CHECK_LAUNCH();
+    } else {  // general form: hash the descendants' keys and look the coordinates up
+      PCC_HIP(hipMemsetAsync(flag, 0, 4, cd->ctx->stream));
+      PCC_TRY(pcc_morton_keys(cd->ctx, qcoords, m, qkeys, flag));
+      PCC_TRY(pcc_lookup(cd->ctx, pre.cs->keys, pre.cs->n, qkeys, m, rows));
+    }
     PCC_TRY(pcc_gather_map_columns(cd->ctx, nbr, 27, pre.cs->n, rows, m, nbr_sub, self));
     PCC_TRY(pcc_sparse_conv(cd->ctx, pre.f, pre.cs->n, nbr_sub, 27, m, m, w, b, cin, cout, 0, conv_o));
     PCC_TRY(pcc_gather_rows_or_zero(cd->ctx, conv_o, self, m, cout, o));
@@ -884,7 +912,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);
   {
     float* params;
-    PCC_TRY(h_s_out_at(cd, gp, yv.coords, ny, &params));
+    PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
     std::vector<float> scale_h((size_t)n_q * cy);
     for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &scale_h[(size_t)q * cy]));
     CODEC_ALLOC(scale_d, float, n_q * cy);
@@ -1129,22 +1157,35 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
   int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
   int n_batch = 0;
+  // The octree's upper levels ARE the stride-16 / stride-32 coordinate sets of the frame (its root cube is aligned to
+  // the same power-of-two grid), so their sizes come out of the geometry decoder and the device never has to report
+  // them back; the leaves of an octree are distinct by construction and the range check is done here on the host.
+  int64_t n16 = 0, n32 = 0;
+  bool out_of_range = false;
   {
     std::vector<int32_t> pts;
     int64_t row = 0;
     for (int f = 0; f < n_frames; ++f) {
       if (fn[f] == 0) continue;
       pts.resize((size_t)fn[f] * 3);
-      PCC_TRY(pcc_octree_unpack(slots[f].p, slots[f].len, pts.data(), fn[f]));
+      int64_t level_n[16];
+      int depth = 0;
+      PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, nullptr, &depth, nullptr));
+      PCC_TRY(pcc_octree_unpack_levels(slots[f].p, slots[f].len, pts.data(), fn[f], level_n));
+      n16 += depth >= 1 ? level_n[depth - 1] : 1;
+      n32 += depth >= 2 ? level_n[depth - 2] : 1;
       for (int64_t i = 0; i < fn[f]; ++i, ++row) {
+        const int32_t x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        out_of_range |= (x < -4096) | (x > 4095) | (y < -4096) | (y > 4095) | (z < -4096) | (z > 4095);
         yc_h[4 * row] = f;
-        yc_h[4 * row + 1] = pts[3 * i] * 8;
-        yc_h[4 * row + 2] = pts[3 * i + 1] * 8;
-        yc_h[4 * row + 3] = pts[3 * i + 2] * 8;
+        yc_h[4 * row + 1] = x * 8;
+        yc_h[4 * row + 2] = y * 8;
+        yc_h[4 * row + 3] = z * 8;
       }
       n_batch = f + 1;
     }
   }
+  PCC_REQUIRE(!out_of_range && n_batch <= 65535, PCC_E_RANGE, "pcc_decode_gop: decoded coordinate out of range");
   ts[1] = now_s() - t0;
 
   // ---- step 3: z coordinates re-derived from the y coordinates, z decoded (codec_parallel.py:291-318)
@@ -1161,13 +1202,8 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
       PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
       PCC_TRY(pcc_morton_keys(ctx, yc, ny, keys, flag));
       PCC_TRY(pcc_sort_pairs(ctx, keys, perm, ny, 0));
-      PCC_TRY(cd->pin_flag.ensure(64));
-      PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
-      int dup = 0;
-      PCC_TRY(pcc_level_counts(ctx, keys, ny, 9, 2, y_level_n.data(), &dup));  // + sizes of the stride-16 / 32 sets
-      PCC_HIP(hipStreamSynchronize(st));
-      PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE, "pcc_decode_gop: decoded coordinate out of range");
-      PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_decode_gop: duplicate latent coordinates");
+      y_level_n[0] = n16;  // from the geometry decoder (above): no read-back, the stream keeps running
+      y_level_n[1] = n32;
     }
     ycs = new_set(cd, keys, ny, 8, std::max(n_batch, 1));
     if (ny > 0) ycs->down_counts = y_level_n;
@@ -1214,7 +1250,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     View yv;
     PCC_TRY(view_of(cd, ycs, &yv));
     float* params;
-    PCC_TRY(h_s_out_at(cd, gp, yv.coords, ny, &params));
+    PCC_TRY(h_s_out_at(cd, gp, ycs, yv, &params));
     std::vector<float> scale_h((size_t)cy);
     PCC_TRY(scale_row(cd, qg, qa, scale_h.data()));
     CODEC_ALLOC(scale_d, float, cy);

@@ -155,7 +155,27 @@ extern "C" int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_po
   return PCC_OK;
 }
 
+static int octree_unpack_impl(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
+                              int64_t* h_level_n);
+
 extern "C" int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points) {
+  return octree_unpack_impl(h_in, len, h_points, cap_points, nullptr);
+}
+
+// the same, and the node count of every level (h_level_n[L], L = 0 .. depth-1; needs 16 entries): level depth-1 is
+// the set of the leaves' parents, depth-2 their grandparents — the decoder's stride-16 / stride-32 coordinate sets
+extern "C" int pcc_octree_unpack_levels(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
+                                        int64_t* h_level_n) {
+  if (!h_level_n) {
+    pcc_set_error("pcc_octree_unpack_levels: null h_level_n");
+    return PCC_E_ARG;
+  }
+  for (int L = 0; L < 16; ++L) h_level_n[L] = 0;
+  return octree_unpack_impl(h_in, len, h_points, cap_points, h_level_n);
+}
+
+static int octree_unpack_impl(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
+                              int64_t* h_level_n) {
   int64_t n = 0;
   int depth = 0;
   int32_t origin[3] = {0, 0, 0};
@@ -182,6 +202,7 @@ extern "C" int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_po
   for (auto& m : model) m = kProbOne / 2;
   std::vector<uint64_t> cur(1, 0ull), nxt;
   for (int L = 0; L < depth; ++L) {
+    if (h_level_n) h_level_n[L] = (int64_t)cur.size();
     nxt.clear();
     for (size_t i = 0; i < cur.size(); ++i) {
       int ones = 0;

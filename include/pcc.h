@@ -392,6 +392,11 @@ int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points,
 /* decode blob to Morton-ordered points int32 [n_points,3] (origin added) */
 int pcc_octree_unpack(const uint8_t* h_in, int64_t len, int32_t* h_points,
                       int64_t cap_points);
+/* the same, and the node count of every octree level (h_level_n[0 .. depth-1],
+ * 16 entries): level depth-1 = the leaves' parents, depth-2 their grandparents,
+ * i.e. the sizes of the stride-2 coordinate sets above the decoded points. */
+int pcc_octree_unpack_levels(const uint8_t* h_in, int64_t len, int32_t* h_points,
+                             int64_t cap_points, int64_t* h_level_n);
 
 /* one-call forms of the geometry slot: pcc_octree_encode = root cube from the
  * first / last key + pcc_octree_levels + pcc_octree_pack (utils.gpcc_encode,
