@@ -171,6 +171,7 @@ struct pcc_codec {
   std::map<std::string, Tensor> t;
   std::map<std::string, float*> dev;  // weights / biases / tables in HBM
   int c_y = 32, c_z = 32;
+  PccRansTables* gc_tables = nullptr;  // coder tables of the Gaussian CDFs, built once (rans_gate.h)
   DevPool pool;
   Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec;
   std::deque<CS> sets;
@@ -637,6 +638,19 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
     }
   cd->c_y = (int)cd->t["g_a.conv3.weight"].dims[2];
   cd->c_z = (int)cd->t["entropy_bottleneck.medians"].dims[0];
+  {
+    const Tensor *gc_cdf = find(cd, "gaussian_conditional.quantized_cdf"), *gc_len = find(cd, "gaussian_conditional.cdf_length"),
+                 *gc_off = find(cd, "gaussian_conditional.offset");
+    if (gc_cdf && gc_len && gc_off)
+      cd->gc_tables = pcc_rans_tables_build(gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(),
+                                            (int)gc_cdf->dims[0]);
+    if (!cd->gc_tables) {
+      for (auto& kv : cd->dev) (void)hipFree(kv.second);
+      pcc_destroy(cd->ctx);
+      delete cd;
+      return nullptr;
+    }
+  }
   return cd;
 }
 
@@ -644,6 +658,7 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
   if (!cd) return;
   if (cd->ctx) (void)pcc_sync(cd->ctx);
   for (auto& kv : cd->dev) (void)hipFree(kv.second);
+  pcc_rans_tables_free(cd->gc_tables);
   cd->pool.release();
   for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec})
     p->release();
@@ -987,7 +1002,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         rcq[q] = pcc_rans_encode16_gated((const int16_t*)cd->pin_ysym.p + (size_t)q * per,
                                          cd->pin_yidx.p + (size_t)q * per, per, gc_cdf->i32(), (int)gc_cdf->dims[1],
                                          gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], y_strings[q].data(), capq,
-                                         &got, &gate);
+                                         &got, &gate, cd->gc_tables);
         if (rcq[q] != PCC_E_NOMEM) break;
         capq = 48 * per + 4096;
       }
@@ -1300,7 +1315,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
                        &up};
       PCC_TRY(pcc_rans_decode8_gated(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1],
                                      gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p,
-                                     &gate));
+                                     &gate, cd->gc_tables));
       PCC_REQUIRE(!up.failed, PCC_E_HIP, "pcc_decode_gop: hipMemcpyAsync of decoded symbols failed");
       PCC_TRY(pcc_gaussian_dequant(ctx, sym_d, params, ny, cy, scale_d, tab->f32()[0], ab->f32()[0], ab->f32()[1], rows));
     }

@@ -14,10 +14,18 @@ struct PccRansGate {
   void (*fn)(void* user, int chunk);
   void* user;
 };
+// Coder tables of a CDF set (per-symbol reciprocals for the encoder, bucket LUTs for the decoder), built once: for the
+// 64 Gaussian tables (27k entries) building them costs ~0.2 ms, which a codec should not pay on every frame.
+// `tables` may be NULL in the calls below (then they are built for the call).
+struct PccRansTables;
+PccRansTables* pcc_rans_tables_build(const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                                     const int32_t* h_offsets, int n_cdf);
+void pcc_rans_tables_free(PccRansTables* t);
 int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
                             int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
-                            uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate);
+                            uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate,
+                            const PccRansTables* tables);
 int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
-                           int32_t* h_sym, const PccRansGate* gate);
+                           int32_t* h_sym, const PccRansGate* gate, const PccRansTables* tables);
 

@@ -26,6 +26,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <algorithm>
+#include <memory>
 #include <thread>
 #include <vector>
 #include "../../include/pcc.h"
@@ -85,28 +86,26 @@ inline int n_nibbles(uint32_t raw) {
   return nb;
 }
 
-template <typename SymT, typename IdxT>
-int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cdfs, int pitch,
-                  const int32_t* sizes, const int32_t* offsets, int n_cdf, uint8_t* out, int64_t cap,
-                  int64_t* len, char* err, size_t errlen, const PccRansGate* gate = nullptr) {
-  // worst case per symbol: 1 main step + (1..2 unary) + 8 raw nibbles; each step emits at most
-  // one 32-bit word, and in-range symbols (the common case) emit 16 bits on average.  Size the
-  // staging buffer for the common case and grow on demand.
-  std::vector<uint32_t> buf((size_t)(n / 2 + n / 8) + 1024);
-  // per-table symbol entries (tables are small: sum of sizes is a few thousand)
-  std::vector<int32_t> base((size_t)n_cdf + 1, 0);
+struct EncTables {
+  std::vector<int32_t> base;  // [n_cdf + 1]: first entry of every table
+  std::vector<EncSym> ent;
+};
+
+int build_enc_tables(const int32_t* cdfs, int pitch, const int32_t* sizes, int n_cdf, EncTables* t, char* err,
+                     size_t errlen) {
+  t->base.assign((size_t)n_cdf + 1, 0);
   for (int c = 0; c < n_cdf; ++c) {
     if (sizes[c] < 2 || sizes[c] > pitch) {
       snprintf(err, errlen, "rans encode: cdf %d has length %d", c, sizes[c]);
       return PCC_E_ARG;
     }
-    base[c + 1] = base[c] + sizes[c] - 1;
+    t->base[c + 1] = t->base[c] + sizes[c] - 1;
   }
-  std::vector<EncSym> ent((size_t)base[n_cdf]);
+  t->ent.resize((size_t)t->base[n_cdf]);
   for (int c = 0; c < n_cdf; ++c) {
     const int32_t* cdf = cdfs + (int64_t)c * pitch;
     for (int v = 0; v < sizes[c] - 1; ++v) {
-      EncSym& e = ent[(size_t)base[c] + v];
+      EncSym& e = t->ent[(size_t)t->base[c] + v];
       const int64_t f = (int64_t)cdf[v + 1] - cdf[v];
       e.freq = (f >= 1 && f <= 65536) ? (uint32_t)f : 0u;   // 0 marks an unusable bin (checked at use)
       e.bias = (uint32_t)cdf[v];
@@ -124,11 +123,34 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
       e.x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)e.freq;
     }
   }
+  return PCC_OK;
+}
+
+template <typename SymT, typename IdxT>
+int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cdfs, int pitch,
+                  const int32_t* sizes, const int32_t* offsets, int n_cdf, uint8_t* out, int64_t cap,
+                  int64_t* len, char* err, size_t errlen, const PccRansGate* gate = nullptr,
+                  const EncTables* pre = nullptr) {
+  // worst case per symbol: 1 main step + (1..2 unary) + 8 raw nibbles; each step emits at most
+  // one 32-bit word, and in-range symbols (the common case) emit 16 bits on average.  Size the
+  // staging buffer for the common case and grow on demand.
+  size_t buf_words = (size_t)(n / 2 + n / 8) + 1024;
+  std::unique_ptr<uint32_t[]> buf(new uint32_t[buf_words]);  // not cleared: 2 MB per 844k symbols
+  // per-table symbol entries: prebuilt (a codec holds them for its lifetime) or built for this call — 27k entries
+  // with a 128-bit division each for the Gaussian tables, ~0.2 ms that a per-frame call should not pay
+  EncTables local;
+  if (!pre) {
+    const int rc = build_enc_tables(cdfs, pitch, sizes, n_cdf, &local, err, errlen);
+    if (rc != PCC_OK) return rc;
+    pre = &local;
+  }
+  const std::vector<int32_t>& base = pre->base;
+  const std::vector<EncSym>& ent = pre->ent;
   for (int attempt = 0; attempt < 3; ++attempt) {
     Enc e;
     e.x = kRansL;
-    e.floor = buf.data();
-    e.ptr = buf.data() + buf.size();
+    e.floor = buf.get();
+    e.ptr = buf.get() + buf_words;
     e.overflow = false;
     const int n_chunks = gate ? gate->n_chunks : 1;
     for (int ch = 0; ch < n_chunks; ++ch) {
@@ -167,10 +189,11 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
     e.emit((uint32_t)(e.x >> 32));
     e.emit((uint32_t)(e.x >> 0));
     if (e.overflow) {
-      buf.assign((size_t)n * 12 + 1024, 0u);  // absolute worst case
+      buf_words = (size_t)n * 12 + 1024;  // absolute worst case
+      buf.reset(new uint32_t[buf_words]);
       continue;
     }
-    const int64_t nbytes = (int64_t)((buf.data() + buf.size()) - e.ptr) * 4;
+    const int64_t nbytes = (int64_t)((buf.get() + buf_words) - e.ptr) * 4;
     if (nbytes > cap) {
       snprintf(err, errlen, "rans encode: output needs %lld bytes, capacity %lld", (long long)nbytes,
                (long long)cap);
@@ -222,10 +245,57 @@ struct DecTab {
 };
 constexpr int kLutBits = 10;
 
+struct DecTables {
+  std::vector<DecTab> tabs;    // [n_cdf]; entries of unused CDFs stay empty
+  std::vector<uint64_t> luts;  // [n_cdf << kLutBits]
+  std::vector<uint32_t> syms;
+};
+
+int build_dec_tables(const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                     const uint8_t* used /*nullable: all*/, DecTables* t, const char* who) {
+  t->tabs.assign((size_t)n_cdf, DecTab{nullptr, nullptr, 0, 0});
+  t->luts.assign((size_t)n_cdf << kLutBits, 0ull);
+  size_t total = 0;
+  for (int c = 0; c < n_cdf; ++c) {
+    if (used && !used[c]) continue;
+    if (h_sizes[c] < 2 || h_sizes[c] > cdf_pitch) {
+      pcc_set_error("%s: cdf %d has length %d", who, c, h_sizes[c]);
+      return PCC_E_ARG;
+    }
+    total += (size_t)h_sizes[c] - 1;
+  }
+  t->syms.assign(total + 1, 0u);
+  total = 0;
+  for (int c = 0; c < n_cdf; ++c) {
+    if (used && !used[c]) continue;
+    const int32_t* cdf = h_cdfs + (int64_t)c * cdf_pitch;
+    const int size = h_sizes[c];
+    uint32_t* sy = t->syms.data() + total;
+    for (int v = 0; v < size - 1; ++v) sy[v] = ((uint32_t)(cdf[v + 1] - cdf[v]) << 16) | ((uint32_t)cdf[v] & 0xFFFFu);
+    // lut[b]: s = largest symbol <= max_value with cdf[s] <= first slot of bucket b, together with its
+    // (start, freq) so that a bucket lying inside ONE symbol's interval resolves with this single load;
+    // a bucket that a CDF boundary cuts is flagged and finishes with the forward scan
+    uint64_t* lut = t->luts.data() + ((size_t)c << kLutBits);
+    int s = 0;
+    for (int b = 0; b < (1 << kLutBits); ++b) {
+      const int lo = b << (16 - kLutBits), hi = lo + (1 << (16 - kLutBits));
+      while (s + 1 < size - 1 && cdf[s + 1] <= lo) ++s;
+      const bool cut = s + 1 < size - 1 && cdf[s + 1] < hi;
+      lut[b] = (uint64_t)sy[s] | ((uint64_t)s << 32) | ((uint64_t)cut << 63);
+    }
+    t->tabs[c].sym = sy;
+    t->tabs[c].lut = lut;
+    t->tabs[c].max_value = size - 2;
+    t->tabs[c].offset = h_offsets[c];
+    total += (size_t)size - 1;
+  }
+  return PCC_OK;
+}
+
 template <typename IdxT>
 int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n, const int32_t* h_cdfs,
                   int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, int32_t* h_sym,
-                  const char* who, const PccRansGate* gate = nullptr) {
+                  const char* who, const PccRansGate* gate = nullptr, const DecTables* pre = nullptr) {
   if (!h_in || len < 8 || n < 0 || (n > 0 && (!h_idx || !h_sym)) || !h_cdfs || !h_sizes || !h_offsets ||
       cdf_pitch < 2 || n_cdf < 1) {
     pcc_set_error("%s: bad argument (len=%lld)", who, (long long)len);
@@ -243,45 +313,16 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
         }
     }
   }
-  // ---- tables of the CDFs that are in use
-  std::vector<uint8_t> used((size_t)n_cdf, 0);
-  for (int64_t i = 0; i < n; ++i) used[(size_t)(int32_t)h_idx[i]] = 1;
-  std::vector<DecTab> tabs((size_t)n_cdf);
-  std::vector<uint64_t> luts((size_t)n_cdf << kLutBits);
-  size_t total = 0;
-  for (int c = 0; c < n_cdf; ++c) {
-    if (!used[c]) continue;
-    if (h_sizes[c] < 2 || h_sizes[c] > cdf_pitch) {
-      pcc_set_error("%s: cdf %d has length %d", who, c, h_sizes[c]);
-      return PCC_E_ARG;
-    }
-    total += (size_t)h_sizes[c] - 1;
+  // ---- tables: prebuilt for every CDF (a codec holds them for its lifetime), or built here for the CDFs in use
+  DecTables local;
+  if (!pre) {
+    std::vector<uint8_t> used((size_t)n_cdf, 0);
+    for (int64_t i = 0; i < n; ++i) used[(size_t)(int32_t)h_idx[i]] = 1;
+    const int rc = build_dec_tables(h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, used.data(), &local, who);
+    if (rc != PCC_OK) return rc;
+    pre = &local;
   }
-  std::vector<uint32_t> syms(total + 1);
-  total = 0;
-  for (int c = 0; c < n_cdf; ++c) {
-    if (!used[c]) continue;
-    const int32_t* cdf = h_cdfs + (int64_t)c * cdf_pitch;
-    const int size = h_sizes[c];
-    uint32_t* sy = syms.data() + total;
-    for (int v = 0; v < size - 1; ++v) sy[v] = ((uint32_t)(cdf[v + 1] - cdf[v]) << 16) | ((uint32_t)cdf[v] & 0xFFFFu);
-    // lut[b]: s = largest symbol <= max_value with cdf[s] <= first slot of bucket b, together with its
-    // (start, freq) so that a bucket lying inside ONE symbol's interval resolves with this single load;
-    // a bucket that a CDF boundary cuts is flagged and finishes with the forward scan
-    uint64_t* lut = luts.data() + ((size_t)c << kLutBits);
-    int s = 0;
-    for (int b = 0; b < (1 << kLutBits); ++b) {
-      const int lo = b << (16 - kLutBits), hi = lo + (1 << (16 - kLutBits));
-      while (s + 1 < size - 1 && cdf[s + 1] <= lo) ++s;
-      const bool cut = s + 1 < size - 1 && cdf[s + 1] < hi;
-      lut[b] = (uint64_t)sy[s] | ((uint64_t)s << 32) | ((uint64_t)cut << 63);
-    }
-    tabs[c].sym = sy;
-    tabs[c].lut = lut;
-    tabs[c].max_value = size - 2;
-    tabs[c].offset = h_offsets[c];
-    total += (size_t)size - 1;
-  }
+  const std::vector<DecTab>& tabs = pre->tabs;
   const uint8_t* p = h_in;
   const uint8_t* const end = h_in + len;
   auto word = [&](bool& bad) -> uint32_t {
@@ -357,9 +398,34 @@ static bool gate_ok(const PccRansGate* g, int64_t n, bool descending) {
   return g->bound[g->n_chunks - 1] == (descending ? 0 : n);
 }
 
+struct PccRansTables {
+  EncTables enc;
+  DecTables dec;
+};
+
+PccRansTables* pcc_rans_tables_build(const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                                     const int32_t* h_offsets, int n_cdf) {
+  if (!h_cdfs || !h_sizes || !h_offsets || cdf_pitch < 2 || n_cdf < 1) {
+    pcc_set_error("pcc_rans_tables_build: bad argument");
+    return nullptr;
+  }
+  std::unique_ptr<PccRansTables> t(new PccRansTables);
+  char err[256] = {0};
+  if (build_enc_tables(h_cdfs, cdf_pitch, h_sizes, n_cdf, &t->enc, err, sizeof(err)) != PCC_OK) {
+    pcc_set_error("pcc_rans_tables_build: %s", err);
+    return nullptr;
+  }
+  if (build_dec_tables(h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, nullptr, &t->dec, "pcc_rans_tables_build") != PCC_OK)
+    return nullptr;
+  return t.release();
+}
+
+void pcc_rans_tables_free(PccRansTables* t) { delete t; }
+
 int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
                             int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
-                            uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate) {
+                            uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate,
+                            const PccRansTables* tables) {
   if (!h_len || n < 0 || (n > 0 && (!h_sym || !h_idx)) || !h_cdfs || !h_sizes || !h_offsets || !h_out ||
       cdf_pitch < 2 || n_cdf < 1 || !gate_ok(gate, n, true)) {
     pcc_set_error("pcc_rans_encode16_gated: bad argument");
@@ -367,20 +433,20 @@ int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t 
   }
   char err[256] = {0};
   const int rc = encode_stream(h_sym, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out, cap, h_len, err,
-                               sizeof(err), gate);
+                               sizeof(err), gate, tables ? &tables->enc : nullptr);
   if (rc != PCC_OK) pcc_set_error("pcc_rans_encode16_gated: %s", err);
   return rc;
 }
 
 int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
-                           int32_t* h_sym, const PccRansGate* gate) {
+                           int32_t* h_sym, const PccRansGate* gate, const PccRansTables* tables) {
   if (!gate_ok(gate, n, false)) {
     pcc_set_error("pcc_rans_decode8_gated: bad chunk table");
     return PCC_E_ARG;
   }
   return decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
-                       "pcc_rans_decode8", gate);
+                       "pcc_rans_decode8", gate, tables ? &tables->dec : nullptr);
 }
 
 extern "C" int pcc_rans_encode(const int32_t* h_sym, const int32_t* h_idx, int64_t n,

@@ -216,8 +216,12 @@ def test_rans_gated_coders_equal_the_plain_ones(oracle):
     FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
     calls = []
     cb = FN(lambda user, c: calls.append(c))
-    enc = getattr(lib, "_Z23pcc_rans_encode16_gatedPKsPKhlPKiiS4_S4_iPhlPlPK11PccRansGate")
-    dec = getattr(lib, "_Z22pcc_rans_decode8_gatedPKhlS0_lPKiiS2_S2_iPiPK11PccRansGate")
+    import subprocess
+    names = subprocess.run(["nm", "-D", pkg("_abi").LIB_PATH], capture_output=True, text=True).stdout.split()
+    enc = getattr(lib, next(n for n in names if "pcc_rans_encode16_gated" in n))
+    dec = getattr(lib, next(n for n in names if "pcc_rans_decode8_gated" in n))
+    build = getattr(lib, next(n for n in names if "pcc_rans_tables_build" in n))
+    build.restype = C.c_void_p
     enc.restype = dec.restype = C.c_int
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     cdf32, sz32, of32 = (np.ascontiguousarray(a, np.int32) for a in (cdf, sizes, offs))
@@ -226,23 +230,30 @@ def test_rans_gated_coders_equal_the_plain_ones(oracle):
     g = Gate(4, bound, C.cast(cb, C.c_void_p), None)
     out = np.zeros(4 * n, np.uint8)
     got = C.c_int64(0)
-    rc = enc(p(sym), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32), C.c_int(len(sz32)),
-             p(out), C.c_int64(out.size), C.byref(got), C.byref(g))
-    assert rc == 0 and bytes(out[:got.value]) == ref and calls == [0, 1, 2, 3]
+    tabs = C.c_void_p(build(p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32), C.c_int(len(sz32))))
+    assert tabs.value
+    for t in (None, tabs):                              # tables built for the call / prebuilt once
+        calls.clear()
+        rc = enc(p(sym), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32),
+                 C.c_int(len(sz32)), p(out), C.c_int64(out.size), C.byref(got), C.byref(g), t)
+        assert rc == 0 and bytes(out[:got.value]) == ref and calls == [0, 1, 2, 3]
 
     calls.clear()
     bound = (C.c_int64 * 3)(64, 99_999, n)              # ascending chunk ends
     g = Gate(3, bound, C.cast(cb, C.c_void_p), None)
     dsym = np.zeros(n, np.int32)
     src = np.frombuffer(ref, np.uint8)
-    rc = dec(p(src), C.c_int64(src.size), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32),
-             C.c_int(len(sz32)), p(dsym), C.byref(g))
-    assert rc == 0 and np.array_equal(dsym, sym.astype(np.int32)) and calls == [0, 1, 2]
+    for t in (None, tabs):
+        calls.clear()
+        dsym[:] = 0
+        rc = dec(p(src), C.c_int64(src.size), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32),
+                 p(of32), C.c_int(len(sz32)), p(dsym), C.byref(g), t)
+        assert rc == 0 and np.array_equal(dsym, sym.astype(np.int32)) and calls == [0, 1, 2]
     # a chunk table that does not cover the array is refused
     bad = (C.c_int64 * 2)(10, n - 1)
     g = Gate(2, bad, C.cast(cb, C.c_void_p), None)
     assert dec(p(src), C.c_int64(src.size), p(idx), C.c_int64(n), p(cdf32), C.c_int(cdf32.shape[1]), p(sz32), p(of32),
-               C.c_int(len(sz32)), p(dsym), C.byref(g)) != 0
+               C.c_int(len(sz32)), p(dsym), C.byref(g), None) != 0
 
 
 def test_rans_decode_rejects_truncated(oracle):
