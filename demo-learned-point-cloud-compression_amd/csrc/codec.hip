@@ -24,6 +24,7 @@
 #include <exception>
 #include <new>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -924,7 +925,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
 
   // ---- step 5: all Q quality streams at once (codec_pipeline.py:397-437)
   t0 = now_s();
-  std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);
+  std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);  // only the int16-overflow path below fills these
+  std::vector<uint8_t> head_done((size_t)n_q, 0);
   {
     float* params;
     PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
@@ -980,6 +982,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     std::vector<int> rcq((size_t)n_q, PCC_OK);
     std::vector<std::string> errq((size_t)n_q);
     int side_rc = PCC_OK;
+    const int64_t nz_for_header = nz;
     auto code_quality = [&](int q) {
       (void)hipSetDevice(cd->device);
       GateUser gu{evc.data(), false};
@@ -997,12 +1000,13 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       }
       if (*(volatile int32_t*)cd->pin_flag.p != 0) return;  // int16 overflow: the generic path below codes everything
       int64_t capq = cap, got = 0;
+      std::unique_ptr<uint8_t[]> ybuf;  // not cleared: a std::vector of the worst-case size would memset 1.7 MB first
       for (int attempt = 0; attempt < 2; ++attempt) {
-        y_strings[q].resize((size_t)capq);
+        ybuf.reset(new uint8_t[(size_t)capq]);
         rcq[q] = pcc_rans_encode16_gated((const int16_t*)cd->pin_ysym.p + (size_t)q * per,
                                          cd->pin_yidx.p + (size_t)q * per, per, gc_cdf->i32(), (int)gc_cdf->dims[1],
-                                         gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], y_strings[q].data(), capq,
-                                         &got, &gate, cd->gc_tables);
+                                         gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], ybuf.get(), capq, &got,
+                                         &gate, cd->gc_tables);
         if (rcq[q] != PCC_E_NOMEM) break;
         capq = 48 * per + 4096;
       }
@@ -1010,7 +1014,20 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         rcq[q] = PCC_E_HIP;
         errq[q] = "hipEventSynchronize failed";
       } else if (rcq[q] == PCC_OK) {
-        y_strings[q].resize((size_t)got);
+        // head of the container (codec_pipeline.py:477-499) + y string, written here in parallel with the other
+        // qualities; the z string, whose length is patched into the header, and the frame slots follow after the join
+        std::vector<uint8_t>& o = cd->out[q];
+        o.clear();
+        o.reserve((size_t)got + 65536);
+        put_be32(o, n_frames);
+        put_be_f64(o, h_q[2 * q]);
+        put_be_f64(o, h_q[2 * q + 1]);
+        put_be32(o, (int32_t)ny);
+        put_be32(o, (int32_t)nz_for_header);
+        put_be32(o, (int32_t)got);
+        put_be32(o, 0);
+        o.insert(o.end(), ybuf.get(), ybuf.get() + got);
+        head_done[q] = 1;
       } else {
         errq[q] = pcc_last_error();
       }
@@ -1036,6 +1053,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     if (*(int32_t*)cd->pin_flag.p == 0) {
       // coded above
     } else {  // a symbol outside int16: the generic int32 form
+      std::fill(head_done.begin(), head_done.end(), 0);
       CODEC_ALLOC(sym32, int32_t, std::max<int64_t>(tot, 1));
       CODEC_ALLOC(idx32, int32_t, std::max<int64_t>(tot, 1));
       PCC_TRY(pcc_gaussian_quant(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
@@ -1065,15 +1083,20 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   t0 = now_s();
   for (int q = 0; q < n_q; ++q) {
     std::vector<uint8_t>& o = cd->out[q];
-    o.clear();
-    put_be32(o, n_frames);
-    put_be_f64(o, h_q[2 * q]);
-    put_be_f64(o, h_q[2 * q + 1]);
-    put_be32(o, (int32_t)ny);
-    put_be32(o, (int32_t)nz);
-    put_be32(o, (int32_t)y_strings[q].size());
-    put_be32(o, (int32_t)z_string.size());
-    o.insert(o.end(), y_strings[q].begin(), y_strings[q].end());
+    if (head_done[q]) {  // header + y string are in place: patch len_z (bytes 32..35, big-endian)
+      const uint32_t lz = (uint32_t)z_string.size();
+      o[32] = (uint8_t)(lz >> 24); o[33] = (uint8_t)(lz >> 16); o[34] = (uint8_t)(lz >> 8); o[35] = (uint8_t)lz;
+    } else {
+      o.clear();
+      put_be32(o, n_frames);
+      put_be_f64(o, h_q[2 * q]);
+      put_be_f64(o, h_q[2 * q + 1]);
+      put_be32(o, (int32_t)ny);
+      put_be32(o, (int32_t)nz);
+      put_be32(o, (int32_t)y_strings[q].size());
+      put_be32(o, (int32_t)z_string.size());
+      o.insert(o.end(), y_strings[q].begin(), y_strings[q].end());
+    }
     o.insert(o.end(), z_string.begin(), z_string.end());
     for (int f = 0; f < n_frames; ++f) {
       put_be32(o, (int32_t)blobs[f].size());

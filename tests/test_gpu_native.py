@@ -114,6 +114,23 @@ def test_native_frame_tables(wl, codec):
         assert [a[q] for q in (1, 2, 3)] == [b[q] for q in (1, 2, 3)]
 
 
+def test_native_symbols_beyond_int16(wl):
+    """colours far outside [0,1] drive latent symbols past +-32767: the compact int16 symbol transfer reports the
+    overflow and the encoder codes the GOP through the generic int32 path (escape-coded symbols) — same containers
+    as the op-by-op engine, and they decode"""
+    cp, dp = pkg("codec_pipeline"), pkg("codec_parallel")
+    frames = [wl.sphere_shell(24, 9.1, seed=2), wl.sphere_shell(20, 7.7, seed=3, offset=(9, -4, 2))]
+    for f in frames:
+        f["colors"] = f["colors"] * 3.0e6 - 1.0e6
+    a, _ = cp.CompressionPipeline(SETTINGS, slots=1).compress(wl.gop([dict(f) for f in frames]))
+    b, _ = cp.CompressionPipeline(SETTINGS, slots=1, engine="ops").compress(wl.gop([dict(f) for f in frames]))
+    assert [a[q] for q in (1, 2, 3)] == [b[q] for q in (1, 2, 3)]
+    ra, _ = dp.DecompressionPipeline(slots=1).decompress(a[3])
+    rb, _ = dp.DecompressionPipeline(slots=1, engine="ops").decompress(b[3])
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x["points"], y["points"]) and np.array_equal(x["colors"], y["colors"])
+
+
 def test_native_errors(codec):
     native = pkg("native")
     pts = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3]], dtype=torch.int32).cuda()
