@@ -1237,7 +1237,12 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   std::vector<int32_t> zsym((size_t)std::max<int64_t>((int64_t)nz_hdr * cz, 1));
   int z_rc = PCC_OK;
   std::string z_err;
-  std::thread helper([&]() {
+  struct WaitAll {  // the job references locals of this frame: never leave it while the job is running
+    PccWorkers& w;
+    ~WaitAll() { w.wait_all(); }
+  } wait_all{cd->workers};
+  cd->workers.ensure(1);
+  cd->workers.run(0, [&]() {
     if (nz_hdr == 0) return;
     std::vector<int32_t> idx((size_t)nz_hdr * cz);
     for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz_hdr, idx.begin() + (size_t)(c + 1) * nz_hdr, c);
@@ -1245,12 +1250,6 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
                            eb_len->i32(), eb_off->i32(), (int)eb_cdf->dims[0], zsym.data());
     if (z_rc != PCC_OK) z_err = pcc_last_error();
   });
-  struct Joiner {
-    std::thread& t;
-    ~Joiner() {
-      if (t.joinable()) t.join();
-    }
-  } joiner{helper};
 
   // ---- step 2: latent coordinates of every frame (codec_parallel.py:266-289)
   t0 = now_s();
@@ -1315,7 +1314,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   PCC_TRY(view_of(cd, zcs, &zv));
   PCC_REQUIRE(zcs->n == nz_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_z=%d, coordinates give %lld", nz_hdr,
               (long long)zcs->n);
-  helper.join();
+  cd->workers.wait_all();
   if (z_rc != PCC_OK) {
     pcc_set_error("pcc_decode_gop (z stream): %s", z_err.c_str());
     return z_rc;
