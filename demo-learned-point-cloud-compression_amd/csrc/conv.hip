@@ -53,6 +53,46 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma(
   }
 
   const bool row_ok = (row0 + i) < n_out;
+  if constexpr (CIN == 4) {
+    // The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound, and with one neighbour-index load and one
+    // gather per offset in sequence every offset paid two dependent memory latencies.  All 27 neighbour indices of the
+    // tile are fetched at once, and the rows and weights of offset k+1 are in flight while offset k is contracted.
+    static_assert(NT == 1, "the 4-channel layer has 32 outputs");
+    int32_t nbs[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) nbs[k] = (row_ok && k < k_vol) ? nbr[(int64_t)k * pitch + row0 + i] : -1;
+    auto rows_of = [&](int32_t nb) -> float4 {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nb >= 0 && lane < 32) v = *reinterpret_cast<const float4*>(in + (int64_t)nb * CIN);
+      return v;
+    };
+    float4 gn = rows_of(nbs[0]);
+    float wn0 = w[(0 + h) * COUT + i], wn1 = w[(2 + h) * COUT + i];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float4 gc = gn;
+      const float wc0 = wn0, wc1 = wn1;
+      if (k + 1 < 27) {
+        gn = rows_of(nbs[k + 1]);  // -1 past k_vol: no load
+        const int kn = k + 1 < k_vol ? k + 1 : k_vol - 1;
+        wn0 = w[((int64_t)kn * CIN + 0 + h) * COUT + i];
+        wn1 = w[((int64_t)kn * CIN + 2 + h) * COUT + i];
+      }
+      if (k < k_vol && __ballot(nbs[k] >= 0) != 0ull) {  // uniform: somebody in this tile has offset k
+        if (lane < 32) {
+          float* d = a + lane * PITCH;
+          d[0] = gc.x; d[1] = gc.y; d[2] = gc.z; d[3] = gc.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i * PITCH + 0 + h], wc0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i * PITCH + 2 + h], wc1, acc[0], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else
   for (int k = 0; k < k_vol; ++k) {
     const int32_t nb = row_ok ? nbr[(int64_t)k * pitch + row0 + i] : -1;
     if (__ballot(nb >= 0) == 0ull) continue;  // nobody in this tile has offset k
