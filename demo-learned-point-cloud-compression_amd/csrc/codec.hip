@@ -1417,6 +1417,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     const std::vector<int64_t>* o0;
     PCC_TRY(offsets_of(cd, h.cs, &o0));
   }
+  const uint32_t* last_keep = nullptr;  // set by the last stage: h.f then still holds the rows of ALL its candidates
   for (int j = 0; j < 3; ++j) {
     Feat u;
     PCC_TRY(up2(cd, "g_s.up" + std::to_string(j), h, 1, &u));
@@ -1453,15 +1454,17 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     if (nu > 0) PCC_TRY(pcc_topk_prune(ctx, logits, nu, nb, offs->data(), kj.data(), keep, nullptr));
     CODEC_ALLOC(pkeys, uint64_t, std::max<int64_t>(n_keep, 1));
     CODEC_ALLOC(pf, float, std::max<int64_t>(n_keep, 1) * cout);
+    const bool last = j == 2 && cout == 32;  // the colour head reads the kept rows in place (pcc_linear_gather below)
     if (n_keep > 0) {
       PCC_TRY(pcc_gather_rows(ctx, u.cs->keys, keep, n_keep, 8, pkeys));
-      PCC_TRY(pcc_gather_rows(ctx, feats, keep, n_keep, 4 * cout, pf));
+      if (!last) PCC_TRY(pcc_gather_rows(ctx, feats, keep, n_keep, 4 * cout, pf));
     }
     CS* ps = new_set(cd, pkeys, n_keep, u.cs->stride, nb);
     ps->offsets = new_offs;
     ps->subset_of = u.cs;
     ps->keep = keep;
-    h = {ps, pf, cout};
+    h = {ps, last ? feats : pf, cout};
+    last_keep = last ? keep : nullptr;
   }
   {
     const float *w, *b;
@@ -1471,7 +1474,14 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     CODEC_ALLOC(rgb, float, std::max<int64_t>(nr, 1) * 3);
     CODEC_ALLOC(coords, int32_t, std::max<int64_t>(nr, 1) * 4);
     if (nr > 0) {
-      PCC_TRY(pcc_linear(ctx, h.f, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
+      if (last_keep && (int)tw->dims[0] == 32 && (int)tw->dims[1] <= 8)
+        PCC_TRY(pcc_linear_gather(ctx, h.f, last_keep, nr, w, b, (int)tw->dims[1], 0, rgb));
+      else if (last_keep) {  // a head the fused form does not cover: gather first
+        CODEC_ALLOC(pf, float, nr * h.c);
+        PCC_TRY(pcc_gather_rows(ctx, h.f, last_keep, nr, 4 * h.c, pf));
+        PCC_TRY(pcc_linear(ctx, pf, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
+      } else
+        PCC_TRY(pcc_linear(ctx, h.f, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
       PCC_TRY(pcc_keys_to_coords(ctx, h.cs->keys, nr, coords));
     }
     cd->rec_coords = coords;

@@ -400,11 +400,14 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ in, in
 // 1x1 with coalesced row reads: a block stages 256 rows (cin*4 B each) through LDS with 16-B
 // lane loads, then thread t runs the fmaf chains of row t (pitch cin+1: conflict-free).  The
 // thread-per-row form above fetches every 128-B line up to 8 times (PMC: 2.2 GB for 0.42 GB of rows).
+// rows (nullable): output row j reads input row rows[j] — the colour head applied to the voxels that survive the last
+// pruning, without first gathering their 128-B feature rows into a tensor of their own.
 template <int CIN>
 __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ in, int64_t n,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias, int cout, int relu,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out,
+                                                     const uint32_t* __restrict__ rows = nullptr) {
   constexpr int PITCH = CIN + 1;
   constexpr int VEC = CIN / 4;  // float4 per row
   __shared__ float tile[256 * PITCH];
@@ -412,7 +415,10 @@ __global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ i
   for (int v = threadIdx.x; v < 256 * VEC; v += 256) {
     const int r = v / VEC, c4 = v - r * VEC;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < n) x = *reinterpret_cast<const float4*>(in + (row0 + r) * CIN + c4 * 4);
+    if (row0 + r < n) {
+      const int64_t src = rows ? (int64_t)rows[row0 + r] : row0 + r;
+      x = *reinterpret_cast<const float4*>(in + src * CIN + c4 * 4);
+    }
     float* d = tile + r * PITCH + c4 * 4;
     d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
   }
@@ -636,11 +642,25 @@ extern "C" int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const floa
   PccProfScope prof(ctx, "linear", n, cin, cout, 1);
   if (!force_scalar() && cin == 32 && cout <= 8 && ((uintptr_t)d_in % 16 == 0)) {
     hipLaunchKernelGGL((k_linear_rows<32>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
-                       d_bias, cout, relu, d_out);
+                       d_bias, cout, relu, d_out, (const uint32_t*)nullptr);
   } else {
     hipLaunchKernelGGL(k_linear, dim3(nblk(n * cout, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
                        d_bias, cin, cout, relu, d_out);
   }
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_linear_gather(pcc_ctx* ctx, const float* d_in, const uint32_t* d_rows, int64_t n, const float* d_w,
+                                 const float* d_bias, int cout, int relu, float* d_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_linear_gather: null ctx");
+  PCC_REQUIRE(cout >= 1 && cout <= 8, PCC_E_ARG, "pcc_linear_gather: cout=%d (1..8; cin is 32)", cout);
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_rows && d_w && d_bias && d_out && (uintptr_t)d_in % 16 == 0, PCC_E_ARG,
+              "pcc_linear_gather: null or misaligned buffers");
+  PccProfScope prof(ctx, "linear", n, 32, cout, 1);
+  hipLaunchKernelGGL((k_linear_rows<32>), dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w, d_bias, cout,
+                     relu, d_out, d_rows);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

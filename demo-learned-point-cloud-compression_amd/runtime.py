@@ -360,6 +360,15 @@ class Runtime:
               "pcc_linear")
         return out
 
+    def linear_gather(self, x, rows, w, b, relu):
+        """linear (cin 32, cout <= 8) on the rows `rows` (int32) of x: [len(rows), cout]"""
+        n, cout = rows.shape[0], w.shape[1]
+        assert x.shape[1] == 32 and w.shape[0] == 32
+        out = self.empty((n, cout), torch.float32)
+        check(self.lib.pcc_linear_gather(self.ctx, _ptr(x), _ptr(rows), n, _ptr(w), _ptr(b), cout, 1 if relu else 0,
+                                         _ptr(out)), "pcc_linear_gather")
+        return out
+
     def topk_prune(self, logits, offsets, k):
         n, nb = logits.shape[0], len(k)
         keep = self.empty((n,), torch.int32)

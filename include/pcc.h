@@ -265,6 +265,13 @@ int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in,
  * heads of g_s. */
 int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const float* d_w,
                const float* d_bias, int cin, int cout, int relu, float* d_out);
+/* pcc_linear (cin = 32, cout <= 8) applied to the rows d_rows[0..n) of d_in:
+ * d_out[j] = linear(d_in[d_rows[j]]) — the colour head on the voxels kept by the
+ * last pruning, without materialising their gathered feature rows (same bits as
+ * pcc_gather_rows followed by pcc_linear). */
+int pcc_linear_gather(pcc_ctx* ctx, const float* d_in, const uint32_t* d_rows,
+                      int64_t n, const float* d_w, const float* d_bias, int cout,
+                      int relu, float* d_out);
 
 /* replaces: the per-frame top-k occupancy pruning inside model.g_s(y_hat,k=ks)
  * (codec_parallel.py:469): within each batch segment keep the k[b] rows with

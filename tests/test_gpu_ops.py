@@ -508,6 +508,18 @@ def test_linear_bit_exact(rt, oracle, cin, cout):
     assert np.array_equal(host(out), oracle.linear(x, w, b))
 
 
+def test_linear_on_gathered_rows(rt, oracle):
+    """the colour head on the kept rows in place (pcc_linear_gather) == gather then linear, == oracle"""
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(5000, 32)).astype(np.float32)
+    rows = np.sort(rng.choice(5000, 1777, replace=False)).astype(np.int32)
+    for cout in (3, 1, 8):
+        w = rng.normal(0, 0.3, (32, cout)).astype(np.float32)
+        b = rng.normal(0, 0.1, cout).astype(np.float32)
+        out = rt.linear_gather(dev(rt, x), dev(rt, rows), dev(rt, w), dev(rt, b), False)
+        assert np.array_equal(host(out), oracle.linear(x[rows], w, b))
+
+
 # ---------------------------------------------------------------- top-k
 @pytest.mark.parametrize("case", ["random", "ties", "all_equal", "k_zero_and_all", "negatives"])
 def test_topk_prune(rt, oracle, case):
