@@ -50,6 +50,7 @@ PROTOTYPES = {
     "pcc_level_counts": (i32, [vp, vp, i64, i32, i32, pi64, C.POINTER(C.c_int)]),
     "pcc_down_coords_known": (i32, [vp, vp, i64, i32, vp, vp, i64, vp, i64]),
     "pcc_exclusive_scan_u32": (i32, [vp, vp, vp, i64, vp]),
+    "pcc_convT_gen_gather": (i32, [vp, vp, vp, i64, vp, vp, i32, vp]),
     "pcc_linear_gather": (i32, [vp, vp, vp, i64, vp, vp, i32, i32, vp]),
     "pcc_gather_map_columns": (i32, [vp, vp, i32, i64, vp, i64, vp, vp]),
     "pcc_subset_map_up": (i32, [vp, vp, i64, vp, vp, i64, vp]),

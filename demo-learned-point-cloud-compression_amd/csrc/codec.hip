@@ -164,6 +164,9 @@ struct Feat {  // sparse tensor = coordinate set + feature rows
   CS* cs = nullptr;
   float* f = nullptr;
   int c = 0;
+  // when set: row i of the tensor is row rows[i] of f (the survivors of a pruning, left in their candidates' tensor;
+  // only up2 and the colour head read such a tensor, both through their *_gather entry points)
+  const uint32_t* rows = nullptr;
 };
 
 }  // namespace
@@ -409,7 +412,12 @@ int up2(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat* y
   CS* c;
   PCC_TRY(up_of(cd, x.cs, &c));
   CODEC_ALLOC(o, float, std::max<int64_t>(c->n, 1) * cout);
-  PCC_TRY(pcc_convT_gen(cd->ctx, x.f, x.cs->n, w, b, cin, cout, relu, o));
+  if (x.rows) {
+    PCC_REQUIRE(cin == 32 && cout == 32, PCC_E_ARG, "codec: row-indirect up stage needs 32 -> 32 channels");
+    PCC_TRY(pcc_convT_gen_gather(cd->ctx, x.f, x.rows, x.cs->n, w, b, relu, o));
+  } else {
+    PCC_TRY(pcc_convT_gen(cd->ctx, x.f, x.cs->n, w, b, cin, cout, relu, o));
+  }
   *y = {c, o, cout};
   return PCC_OK;
 }
@@ -1417,7 +1425,6 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     const std::vector<int64_t>* o0;
     PCC_TRY(offsets_of(cd, h.cs, &o0));
   }
-  const uint32_t* last_keep = nullptr;  // set by the last stage: h.f then still holds the rows of ALL its candidates
   for (int j = 0; j < 3; ++j) {
     Feat u;
     PCC_TRY(up2(cd, "g_s.up" + std::to_string(j), h, 1, &u));
@@ -1454,17 +1461,17 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     if (nu > 0) PCC_TRY(pcc_topk_prune(ctx, logits, nu, nb, offs->data(), kj.data(), keep, nullptr));
     CODEC_ALLOC(pkeys, uint64_t, std::max<int64_t>(n_keep, 1));
     CODEC_ALLOC(pf, float, std::max<int64_t>(n_keep, 1) * cout);
-    const bool last = j == 2 && cout == 32;  // the colour head reads the kept rows in place (pcc_linear_gather below)
+    // the kept rows stay where they are: the next up stage / the colour head read them through `keep`
+    const bool in_place = cout == 32;
     if (n_keep > 0) {
       PCC_TRY(pcc_gather_rows(ctx, u.cs->keys, keep, n_keep, 8, pkeys));
-      if (!last) PCC_TRY(pcc_gather_rows(ctx, feats, keep, n_keep, 4 * cout, pf));
+      if (!in_place) PCC_TRY(pcc_gather_rows(ctx, feats, keep, n_keep, 4 * cout, pf));
     }
     CS* ps = new_set(cd, pkeys, n_keep, u.cs->stride, nb);
     ps->offsets = new_offs;
     ps->subset_of = u.cs;
     ps->keep = keep;
-    h = {ps, last ? feats : pf, cout};
-    last_keep = last ? keep : nullptr;
+    h = {ps, in_place ? feats : pf, cout, in_place ? keep : nullptr};
   }
   {
     const float *w, *b;
@@ -1474,11 +1481,11 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     CODEC_ALLOC(rgb, float, std::max<int64_t>(nr, 1) * 3);
     CODEC_ALLOC(coords, int32_t, std::max<int64_t>(nr, 1) * 4);
     if (nr > 0) {
-      if (last_keep && (int)tw->dims[0] == 32 && (int)tw->dims[1] <= 8)
-        PCC_TRY(pcc_linear_gather(ctx, h.f, last_keep, nr, w, b, (int)tw->dims[1], 0, rgb));
-      else if (last_keep) {  // a head the fused form does not cover: gather first
+      if (h.rows && (int)tw->dims[0] == 32 && (int)tw->dims[1] <= 8)
+        PCC_TRY(pcc_linear_gather(ctx, h.f, h.rows, nr, w, b, (int)tw->dims[1], 0, rgb));
+      else if (h.rows) {  // a head the fused form does not cover: gather first
         CODEC_ALLOC(pf, float, nr * h.c);
-        PCC_TRY(pcc_gather_rows(ctx, h.f, last_keep, nr, 4 * h.c, pf));
+        PCC_TRY(pcc_gather_rows(ctx, h.f, h.rows, nr, 4 * h.c, pf));
         PCC_TRY(pcc_linear(ctx, pf, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
       } else
         PCC_TRY(pcc_linear(ctx, h.f, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));

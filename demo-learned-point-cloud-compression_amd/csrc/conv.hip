@@ -303,10 +303,12 @@ __global__ __launch_bounds__(256) void k_gconv_scalar(
 }
 
 // generative transposed convolution, kernel 2 stride 2: out[8p+o] = W[o]^T in[p] + b
+// rows (nullable): parent p reads input row rows[p] — the up stage right after a pruning, on the kept rows in place
 template <int NT>
 __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
     const float* __restrict__ in, int64_t n_in, const float* __restrict__ w,
-    const float* __restrict__ bias, int relu, float* __restrict__ out) {
+    const float* __restrict__ bias, int relu, float* __restrict__ out,
+    const uint32_t* __restrict__ rows = nullptr) {
   constexpr int CIN = 32;
   constexpr int COUT = NT * 32;
   constexpr int PITCH = CIN + 1;
@@ -320,7 +322,10 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
   for (int it = 0; it < 4; ++it) {
     const int r = it * 8 + (lane >> 3), chunk = lane & 7;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < n_in) v = *reinterpret_cast<const float4*>(in + (row0 + r) * CIN + chunk * 4);
+    if (row0 + r < n_in) {
+      const int64_t src = rows ? (int64_t)rows[row0 + r] : row0 + r;
+      v = *reinterpret_cast<const float4*>(in + src * CIN + chunk * 4);
+    }
     float* d = a + r * PITCH + chunk * 4;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
@@ -620,10 +625,10 @@ extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, cons
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
   if (!force_scalar() && aligned && cin == 32 && cout == 32) {
     hipLaunchKernelGGL((k_convT_mfma<1>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
-                       d_in, n_in, d_w, d_bias, relu, d_out);
+                       d_in, n_in, d_w, d_bias, relu, d_out, (const uint32_t*)nullptr);
   } else if (!force_scalar() && aligned && cin == 32 && cout == 64) {
     hipLaunchKernelGGL((k_convT_mfma<2>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
-                       d_in, n_in, d_w, d_bias, relu, d_out);
+                       d_in, n_in, d_w, d_bias, relu, d_out, (const uint32_t*)nullptr);
   } else {
     hipLaunchKernelGGL(k_convT_scalar, dim3(nblk(n_in * 8 * cout, 256)), dim3(256), 0, st, d_in, n_in,
                        d_w, d_bias, cin, cout, relu, d_out);
@@ -647,6 +652,19 @@ extern "C" int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const floa
     hipLaunchKernelGGL(k_linear, dim3(nblk(n * cout, 256)), dim3(256), 0, ctx->stream, d_in, n, d_w,
                        d_bias, cin, cout, relu, d_out);
   }
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_convT_gen_gather(pcc_ctx* ctx, const float* d_in, const uint32_t* d_rows, int64_t n_in,
+                                    const float* d_w, const float* d_bias, int relu, float* d_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_convT_gen_gather: null ctx");
+  if (n_in <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_rows && d_w && d_bias && d_out && (uintptr_t)d_in % 16 == 0, PCC_E_ARG,
+              "pcc_convT_gen_gather: null or misaligned buffers");
+  PccProfScope prof(ctx, "convT_gen", n_in, 32, 32, 8);
+  hipLaunchKernelGGL((k_convT_mfma<1>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, ctx->stream, d_in,
+                     n_in, d_w, d_bias, relu, d_out, d_rows);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -360,6 +360,15 @@ class Runtime:
               "pcc_linear")
         return out
 
+    def convT_gen_gather(self, x, rows, w, b, relu):
+        """convT_gen (32 -> 32) whose parent p is row rows[p] of x: [8 len(rows), 32]"""
+        n = rows.shape[0]
+        assert x.shape[1] == 32 and w.shape == (8, 32, 32)
+        out = self.empty((8 * n, 32), torch.float32)
+        check(self.lib.pcc_convT_gen_gather(self.ctx, _ptr(x), _ptr(rows), n, _ptr(w), _ptr(b), 1 if relu else 0,
+                                            _ptr(out)), "pcc_convT_gen_gather")
+        return out
+
     def linear_gather(self, x, rows, w, b, relu):
         """linear (cin 32, cout <= 8) on the rows `rows` (int32) of x: [len(rows), cout]"""
         n, cout = rows.shape[0], w.shape[1]

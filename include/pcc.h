@@ -265,6 +265,12 @@ int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in,
  * heads of g_s. */
 int pcc_linear(pcc_ctx* ctx, const float* d_in, int64_t n, const float* d_w,
                const float* d_bias, int cin, int cout, int relu, float* d_out);
+/* pcc_convT_gen (cin = cout = 32) whose parent p is row d_rows[p] of d_in: the up
+ * stage that follows a pruning, on the kept rows in place (same bits as
+ * pcc_gather_rows followed by pcc_convT_gen). */
+int pcc_convT_gen_gather(pcc_ctx* ctx, const float* d_in, const uint32_t* d_rows,
+                         int64_t n_in, const float* d_w, const float* d_bias,
+                         int relu, float* d_out);
 /* pcc_linear (cin = 32, cout <= 8) applied to the rows d_rows[0..n) of d_in:
  * d_out[j] = linear(d_in[d_rows[j]]) — the colour head on the voxels kept by the
  * last pruning, without materialising their gathered feature rows (same bits as

@@ -508,6 +508,16 @@ def test_linear_bit_exact(rt, oracle, cin, cout):
     assert np.array_equal(host(out), oracle.linear(x, w, b))
 
 
+def test_convT_on_gathered_rows(rt, oracle):
+    """the up stage on the kept rows in place (pcc_convT_gen_gather) == gather then convT, == oracle"""
+    rng = np.random.default_rng(10)
+    x = rng.normal(size=(3000, 32)).astype(np.float32)
+    rows = np.sort(rng.choice(3000, 1001, replace=False)).astype(np.int32)
+    w, b = _weights(rng, 8, 32, 32)
+    out = rt.convT_gen_gather(dev(rt, x), dev(rt, rows), dev(rt, w), dev(rt, b), True)
+    assert np.array_equal(host(out), oracle.convT(x[rows], w, b, True))
+
+
 def test_linear_on_gathered_rows(rt, oracle):
     """the colour head on the kept rows in place (pcc_linear_gather) == gather then linear, == oracle"""
     rng = np.random.default_rng(9)
