@@ -300,6 +300,19 @@ def test_octree_host_coder_matches_oracle(oracle, n, extent, lo):
     assert np.array_equal(oracle.octree_decode(blob), dec)
     with pytest.raises(runtime.PccError):
         runtime.octree_unpack(blob[:-4] if len(blob) > 28 else blob[:10])
+    # pcc_octree_unpack_levels: same points, and the node counts of the levels — the two levels above the leaves are
+    # the stride-16 / stride-32 coordinate sets the decoder builds next (its pyramid sizes without a device read-back)
+    import ctypes as C
+    lib = pkg("_abi").lib()
+    buf = np.frombuffer(blob, np.uint8)
+    out = np.zeros((n, 3), np.int32)
+    lv = (C.c_int64 * 16)()
+    assert lib.pcc_octree_unpack_levels(buf.ctypes.data_as(C.c_void_p), len(blob), out.ctypes.data_as(C.c_void_p), n,
+                                        lv) == 0
+    assert np.array_equal(out, dec) and [lv[i] for i in range(depth)] == [len(l) for l in levels]
+    k16, _ = oracle.down(keys, 8)
+    k32, _ = oracle.down(k16, 16)
+    assert lv[depth - 1] == len(k16) and (lv[depth - 2] if depth >= 2 else 1) == len(k32)
 
 
 def test_octree_empty_frame(oracle):
