@@ -185,8 +185,8 @@ struct PccWorkers {
     std::unique_lock<std::mutex> lk(m);
     while ((int)th.size() < n) {
       const int i = (int)th.size();
-      job.emplace_back();
-      busy.push_back(0);
+      job.resize((size_t)i + 1);   // slots first: a thread that fails to start must not leave run(i) without a worker
+      busy.resize((size_t)i + 1, 0);
       th.emplace_back([this, i]() {
         std::unique_lock<std::mutex> l(m);
         for (;;) {
