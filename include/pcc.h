@@ -184,7 +184,9 @@ int pcc_inverse_rows(pcc_ctx* ctx, const uint32_t* d_rows, int64_t m, int64_t n,
                      int32_t* d_remap);
 
 /* replaces: ME kernel-map generation for 3^3 stride-1 convolutions.
- * stride = tensor stride ts; d_nbr is [27, n]. */
+ * stride = tensor stride ts; d_nbr is [27, n].  d_keys = the rows of a coordinate
+ * set: Morton-sorted, distinct (as pcc_sort_pairs / pcc_down_coords / pcc_up_coords
+ * leave them); sets of <= 4096 rows are searched in LDS, larger ones hashed. */
 int pcc_build_map(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int stride,
                   int32_t* d_nbr);
 /* replaces: SparseTensor.features_at_coordinates (codec_pipeline.py:401,
