@@ -39,6 +39,11 @@ double now_s() {
 }
 
 constexpr int64_t kHashBuildMax = 60000;  // levels up to this many voxels hash directly; larger ones derive
+// Decoder limits on what a container may ANNOUNCE before its streams have been decoded (a receiver is fed network bytes):
+// latent rows per GOP (2^27 rows = a GOP of several 10^9 input points, beyond what 288 GB hold), and the number of z
+// symbols for which the z job may start — and size its buffers — ahead of the geometry decode that verifies the counts.
+constexpr int64_t kMaxLatentRows = (int64_t)1 << 27;
+constexpr int64_t kEarlyZSymbols = (int64_t)1 << 22;
 
 int log2i(int ts) {
   int s = 0;
@@ -1226,23 +1231,39 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   // count far beyond what the payload can hold is a corrupt header, not a big frame
   int64_t ny = 0;
   std::vector<int64_t> fn((size_t)n_frames, 0);
+  std::vector<int> fdepth((size_t)n_frames, 0);
   for (int f = 0; f < n_frames; ++f) {
-    int depth;
     int32_t org[3];
-    PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, &fn[f], &depth, org));
+    PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, &fn[f], &fdepth[f], org));
     PCC_REQUIRE(fn[f] >= 0 && fn[f] <= ((int64_t)slots[f].len + 64) * 4096, PCC_E_STREAM,
                 "pcc_decode_gop: frame %d announces %lld points in a %d-byte blob", f, (long long)fn[f], slots[f].len);
+    // The root cube must sit on the 2^depth grid of the biased latent lattice, as octree_root() places it: only then
+    // are the octree's upper levels the frame's stride-16 / stride-32 coordinate sets, whose sizes the device path
+    // below takes from the geometry decoder without a read-back.  An origin off that grid (a flipped bit in the 12
+    // origin bytes passes every other check) would make those counts too small for the kernels that trust them.
+    if (fn[f] > 0) {
+      const int d = fdepth[f];
+      PCC_REQUIRE(d >= 1 && d <= 13, PCC_E_STREAM, "pcc_decode_gop: frame %d: octree depth %d", f, d);
+      for (int a = 0; a < 3; ++a) {
+        const int64_t biased = (int64_t)org[a] + 4096;
+        PCC_REQUIRE(biased >= 0 && biased + ((int64_t)1 << d) <= 8192 && (biased & (((int64_t)1 << d) - 1)) == 0,
+                    PCC_E_STREAM, "pcc_decode_gop: frame %d: octree origin %d (axis %d) is not on the 2^%d grid", f,
+                    org[a], a, d);
+      }
+    }
     ny += fn[f];
   }
   PCC_REQUIRE(ny == ny_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_y=%d, geometry gives %lld", ny_hdr,
               (long long)ny);
   PCC_REQUIRE(nz_hdr <= ny_hdr, PCC_E_STREAM, "pcc_decode_gop: container says N_z=%d > N_y=%d", nz_hdr, ny_hdr);
+  PCC_REQUIRE(ny_hdr <= kMaxLatentRows, PCC_E_STREAM, "pcc_decode_gop: container says N_y=%d, this build decodes at most %lld",
+              ny_hdr, (long long)kMaxLatentRows);
 
   // z string: nothing from the GPU is needed, decode it on a helper thread right away
   const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
                *eb_off = find(cd, "entropy_bottleneck.offset");
   PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_decode_gop: entropy_bottleneck tables missing");
-  std::vector<int32_t> zsym((size_t)std::max<int64_t>((int64_t)nz_hdr * cz, 1));
+  std::vector<int32_t> zsym;
   int z_rc = PCC_OK;
   std::string z_err;
   struct WaitAll {  // the job references locals of this frame: never leave it while the job is running
@@ -1250,37 +1271,52 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     ~WaitAll() { w.wait_all(); }
   } wait_all{cd->workers};
   cd->workers.ensure(1);
-  cd->workers.run(0, [&]() {
-    if (nz_hdr == 0) return;
-    std::vector<int32_t> idx((size_t)nz_hdr * cz);
-    for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz_hdr, idx.begin() + (size_t)(c + 1) * nz_hdr, c);
-    z_rc = pcc_rans_decode(zstr, zlen, idx.data(), (int64_t)nz_hdr * cz, eb_cdf->i32(), (int)eb_cdf->dims[1],
-                           eb_len->i32(), eb_off->i32(), (int)eb_cdf->dims[0], zsym.data());
-    if (z_rc != PCC_OK) z_err = pcc_last_error();
-  });
+  auto start_z_job = [&]() {
+    zsym.resize((size_t)std::max<int64_t>((int64_t)nz_hdr * cz, 1));
+    cd->workers.run(0, [&]() {
+      if (nz_hdr == 0) return;
+      std::vector<int32_t> idx((size_t)nz_hdr * cz);
+      for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz_hdr, idx.begin() + (size_t)(c + 1) * nz_hdr, c);
+      z_rc = pcc_rans_decode(zstr, zlen, idx.data(), (int64_t)nz_hdr * cz, eb_cdf->i32(), (int)eb_cdf->dims[1],
+                             eb_len->i32(), eb_off->i32(), (int)eb_cdf->dims[0], zsym.data());
+      if (z_rc != PCC_OK) z_err = pcc_last_error();
+    });
+  };
+  // N_z is still only an announced number here.  Up to kEarlyZSymbols symbols (16 MB of buffers) the job starts at once
+  // and overlaps the geometry decode; a container announcing more waits until the geometry streams have confirmed N_y.
+  const bool z_early = (int64_t)nz_hdr * cz <= kEarlyZSymbols;
+  if (z_early) start_z_job();
 
   // ---- step 2: latent coordinates of every frame (codec_parallel.py:266-289)
   t0 = now_s();
+  // Every frame's stream is decoded into a vector that grows with what the stream holds; only after all of them have
+  // confirmed their announced counts is anything sized from N_y.
+  // The octree's upper levels ARE the stride-16 / stride-32 coordinate sets of the frame (its root cube is aligned to
+  // the same power-of-two grid — checked above), so their sizes come out of the geometry decoder and the device never
+  // has to report them back; the leaves of an octree are distinct by construction and the range check is done here on
+  // the host.
+  int n_batch = 0;
+  int64_t n16 = 0, n32 = 0;
+  std::vector<std::vector<int32_t>> fpts((size_t)n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    if (fn[f] == 0) continue;
+    int64_t level_n[16];
+    PCC_TRY(pcc_octree_unpack_vec(slots[f].p, slots[f].len, &fpts[f], level_n));
+    PCC_REQUIRE((int64_t)fpts[f].size() == 3 * fn[f], PCC_E_STREAM, "pcc_decode_gop: frame %d decoded %zu points, announced %lld",
+                f, fpts[f].size() / 3, (long long)fn[f]);
+    const int depth = fdepth[f];
+    n16 += depth >= 1 ? level_n[depth - 1] : 1;
+    n32 += depth >= 2 ? level_n[depth - 2] : 1;
+    n_batch = f + 1;
+  }
+  if (!z_early) start_z_job();
   PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
   int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
-  int n_batch = 0;
-  // The octree's upper levels ARE the stride-16 / stride-32 coordinate sets of the frame (its root cube is aligned to
-  // the same power-of-two grid), so their sizes come out of the geometry decoder and the device never has to report
-  // them back; the leaves of an octree are distinct by construction and the range check is done here on the host.
-  int64_t n16 = 0, n32 = 0;
   bool out_of_range = false;
   {
-    std::vector<int32_t> pts;
     int64_t row = 0;
     for (int f = 0; f < n_frames; ++f) {
-      if (fn[f] == 0) continue;
-      pts.resize((size_t)fn[f] * 3);
-      int64_t level_n[16];
-      int depth = 0;
-      PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, nullptr, &depth, nullptr));
-      PCC_TRY(pcc_octree_unpack_levels(slots[f].p, slots[f].len, pts.data(), fn[f], level_n));
-      n16 += depth >= 1 ? level_n[depth - 1] : 1;
-      n32 += depth >= 2 ? level_n[depth - 2] : 1;
+      const int32_t* pts = fpts[f].data();
       for (int64_t i = 0; i < fn[f]; ++i, ++row) {
         const int32_t x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
         out_of_range |= (x < -4096) | (x > 4095) | (y < -4096) | (y > 4095) | (z < -4096) | (z > 4095);
@@ -1289,7 +1325,6 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
         yc_h[4 * row + 2] = y * 8;
         yc_h[4 * row + 3] = z * 8;
       }
-      n_batch = f + 1;
     }
   }
   PCC_REQUIRE(!out_of_range && n_batch <= 65535, PCC_E_RANGE, "pcc_decode_gop: decoded coordinate out of range");

@@ -18,6 +18,7 @@
 #include <string.h>
 #include <vector>
 #include "../../include/pcc.h"
+#include "rans_gate.h"
 
 void pcc_set_error(const char* fmt, ...);
 
@@ -174,19 +175,16 @@ extern "C" int pcc_octree_unpack_levels(const uint8_t* h_in, int64_t len, int32_
   return octree_unpack_impl(h_in, len, h_points, cap_points, h_level_n);
 }
 
-static int octree_unpack_impl(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
-                              int64_t* h_level_n) {
+// occupancy stream -> Morton cell indexes of the leaves (relative to the root cube), in coding order.  Memory grows
+// with what the stream actually holds, never with the announced point count.
+static int octree_decode_cells(const uint8_t* h_in, int64_t len, std::vector<uint64_t>* cells, int64_t* h_level_n,
+                               int32_t origin[3]) {
   int64_t n = 0;
   int depth = 0;
-  int32_t origin[3] = {0, 0, 0};
   const int r = pcc_octree_peek(h_in, len, &n, &depth, origin);
   if (r != PCC_OK) return r;
+  cells->clear();
   if (n == 0) return PCC_OK;
-  if (!h_points || cap_points < n) {
-    pcc_set_error("pcc_octree_unpack: output capacity %lld < %lld points", (long long)cap_points,
-                  (long long)n);
-    return PCC_E_ARG;
-  }
   const uint8_t* p = h_in + kHeader;
   const uint8_t* end = p + get_u32(h_in + 20);
   auto word = [&](bool& bad) -> uint32_t {
@@ -237,11 +235,45 @@ static int octree_unpack_impl(const uint8_t* h_in, int64_t len, int32_t* h_point
     pcc_set_error("pcc_octree_unpack: decoded %zu points, header says %lld", cur.size(), (long long)n);
     return PCC_E_STREAM;
   }
-  for (int64_t i = 0; i < n; ++i) {
-    const uint64_t k = cur[(size_t)i];
-    h_points[3 * i + 0] = (int32_t)compact3(k >> 2) + origin[0];
-    h_points[3 * i + 1] = (int32_t)compact3(k >> 1) + origin[1];
-    h_points[3 * i + 2] = (int32_t)compact3(k) + origin[2];
+  cells->swap(cur);
+  return PCC_OK;
+}
+
+static inline void cell_point(uint64_t k, const int32_t origin[3], int32_t* out) {
+  out[0] = (int32_t)compact3(k >> 2) + origin[0];
+  out[1] = (int32_t)compact3(k >> 1) + origin[1];
+  out[2] = (int32_t)compact3(k) + origin[2];
+}
+
+static int octree_unpack_impl(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
+                              int64_t* h_level_n) {
+  int64_t n = 0;
+  int depth = 0;
+  int32_t origin[3] = {0, 0, 0};
+  const int r = pcc_octree_peek(h_in, len, &n, &depth, origin);
+  if (r != PCC_OK) return r;
+  if (n == 0) return PCC_OK;
+  if (!h_points || cap_points < n) {
+    pcc_set_error("pcc_octree_unpack: output capacity %lld < %lld points", (long long)cap_points,
+                  (long long)n);
+    return PCC_E_ARG;
   }
+  std::vector<uint64_t> cells;
+  const int rc = octree_decode_cells(h_in, len, &cells, h_level_n, origin);
+  if (rc != PCC_OK) return rc;
+  for (int64_t i = 0; i < n; ++i) cell_point(cells[(size_t)i], origin, h_points + 3 * i);
+  return PCC_OK;
+}
+
+// internal (rans_gate.h): the same into a vector sized by what was DECODED — for callers holding untrusted blobs,
+// which must not size anything from the announced count before the stream has confirmed it
+int pcc_octree_unpack_vec(const uint8_t* h_in, int64_t len, std::vector<int32_t>* pts, int64_t* h_level_n /*[16]*/) {
+  for (int L = 0; L < 16; ++L) h_level_n[L] = 0;
+  std::vector<uint64_t> cells;
+  int32_t origin[3] = {0, 0, 0};
+  const int rc = octree_decode_cells(h_in, len, &cells, h_level_n, origin);
+  if (rc != PCC_OK) return rc;
+  pts->resize(cells.size() * 3);
+  for (size_t i = 0; i < cells.size(); ++i) cell_point(cells[i], origin, pts->data() + 3 * i);
   return PCC_OK;
 }

@@ -34,6 +34,7 @@ __global__ void k_emit_parents(const uint64_t* __restrict__ keys, int64_t n, int
   const uint64_t k = keys[i];
   const uint32_t f = flags[i];
   const int64_t p = (int64_t)excl[i] + f - 1;
+  if (p >= m) return;  // a caller-supplied m smaller than the real parent count (pcc_down_coords_known): never write past it
   const int o = (int)((k >> cshift) & 7ull);
   if (f) pkeys[p] = (k >> (cshift + 3)) << (cshift + 3);
   nbr8[(int64_t)o * m + p] = (int32_t)i;

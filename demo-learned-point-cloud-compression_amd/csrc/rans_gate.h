@@ -1,6 +1,7 @@
 // rans_gate.h — internal (not part of the C-ABI): chunk gates of the host rANS coders.
 #pragma once
 #include <stdint.h>
+#include <vector>
 
 // Host rANS coders working through a buffer that is still crossing PCIe (rans_host.cpp; used by codec.hip).
 // The flattened symbol array is cut into chunks; `fn(user, c)` is called
@@ -29,3 +30,7 @@ int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_id
                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
                            int32_t* h_sym, const PccRansGate* gate, const PccRansTables* tables);
 
+
+// octree_host.cpp: pcc_octree_unpack_levels into a vector that is sized by what the stream actually DECODED, not by
+// the point count its header announces (decoders of untrusted containers; h_level_n needs 16 entries).
+int pcc_octree_unpack_vec(const uint8_t* h_in, int64_t len, std::vector<int32_t>* pts, int64_t* h_level_n);

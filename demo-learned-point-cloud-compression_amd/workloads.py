@@ -8,8 +8,11 @@ import numpy as np
 
 
 def _dedup(pts):
-    pts = np.unique(pts.astype(np.int64), axis=0)
-    return pts
+    """unique rows in lexicographic (x, y, z) order — np.unique(axis=0)'s result, through packed 63-bit keys"""
+    p = pts.astype(np.int64)
+    bias, mask = 1 << 20, (1 << 21) - 1
+    k = np.unique(((p[:, 0] + bias) << 42) | ((p[:, 1] + bias) << 21) | (p[:, 2] + bias))
+    return np.stack([(k >> 42) - bias, ((k >> 21) & mask) - bias, (k & mask) - bias], 1)
 
 
 def _colors(pts, rng, noise=0.02):
@@ -153,6 +156,20 @@ def tiled_scan(tiles=8, n_per_tile=500_000, seed=0):
         off = (-200 + 40 * (t & 1), -150 + 30 * ((t >> 1) & 1), -100 + 20 * ((t >> 2) & 1))
         out.append(room(n_per_tile, seed=seed + 1 + t, offset=off))
     return out
+
+
+def fused_scan(n_total=4_000_000, seed=0, extent=(512, 512, 256)):
+    """C5 as ONE frame: a fused indoor scan of 2x2x2 C2-style rooms side by side (1024 x 1024 x 512 voxels at the
+    default extent, origin at the centre), n_total / 8 voxels per room; `tiled.cut_tiles` with blocks of one room
+    cuts it back into the 8 octree blocks"""
+    ex = np.asarray(extent)
+    pts, cols = [], []
+    for t in range(8):
+        o = np.array([(t >> 2) & 1, (t >> 1) & 1, t & 1]) * ex - ex
+        f = room(n_total // 8, extent=extent, seed=seed + 101 + t, offset=tuple(int(v) for v in o))
+        pts.append(f["points"])
+        cols.append(f["colors"])
+    return {"points": np.concatenate(pts, 0), "colors": np.concatenate(cols, 0)}
 
 
 def gop(frames):

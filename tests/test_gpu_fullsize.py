@@ -1,11 +1,17 @@
-"""BASELINE.json's full-size configurations on the GPU, checked through size-independent
-properties (the oracle takes minutes at these sizes, so it is used only on the
-geometry-only case where it is cheap):
+"""BASELINE.json's full-size configurations on the GPU: container bytes of every quality and the decoded
+frames compared with the CPU oracle AT FULL SIZE (the oracle codes a 1M-point frame in a few seconds), plus
+size-independent properties.
 
-  C2  1M-point ScanNet-scale frame, hyperprior model  — round trip, container structure
+  C2  1M-point ScanNet-scale frame, hyperprior model  — bytes + reconstruction = oracle; round trip, container structure
   C3  ~120k-point LiDAR sweep, geometry-only octree   — lossless, equals the oracle's blob
-  C4  ~800k-point dense body with RGB                 — round trip
+  C4  ~800k-point dense body with RGB                 — bytes + reconstruction = oracle; round trip
+  C5  4M-point scan in 8 tiles                        — tests/test_gpu_tiled.py
   multi-frame GOP with empty-ish and tiny frames      — per-frame bookkeeping
+
+The full-size comparisons are the only ones that run the large-layer kernels where they ship: the four-windows-per-
+workgroup conv on 3.26M candidate rows (int32 row arithmetic (pr << 3) | o, several rounds of XCD windows, grid
+round-up past the last row), the radix sort on 1M keys, top-k over millions of logits.
+(reference: sender/encoder/codec_pipeline.py:196-236, receiver/decoder/codec_parallel.py:141-171)
 """
 import struct
 
@@ -46,6 +52,23 @@ def parse(container):
 def stride_counts(points, s):
     """voxel count of a frame at stride s: unique(floor(p / s))"""
     return np.unique(np.floor_divide(points.astype(np.int64), s), axis=0).shape[0]
+
+
+def check_oracle_parity(codec, oracle, wl, frames):
+    """container bytes of all qualities and the decoded frames of every quality equal the oracle's"""
+    enc, dec = codec
+    ref, _ = oracle.compress([dict(f) for f in frames], SETTINGS)
+    out, _ = enc.compress(wl.gop([dict(f) for f in frames]))
+    for q in (1, 2, 3):
+        assert len(out[q]) == len(ref[q]), f"container {q}: {len(out[q])} bytes, oracle {len(ref[q])}"
+        assert out[q] == ref[q], f"container {q} differs from the oracle"
+    for q in (1, 3):
+        oref = oracle.decompress(ref[q])
+        rec, _ = dec.decompress(out[q])
+        assert len(rec) == len(oref) == len(frames)
+        for a, b in zip(rec, oref):
+            assert np.array_equal(a["points"], b["points"]), f"quality {q}: decoded occupancy differs"
+            assert np.array_equal(a["colors"], b["colors"]), f"quality {q}: decoded colours differ"
 
 
 def check_roundtrip(codec, wl, frames):
@@ -100,10 +123,25 @@ def test_c2_scannet_scale_1m(codec, wl):
     assert all(0.3 < b < 12 for b in side["gop_info"]["bpp"][1:])
 
 
+def test_c2_scannet_scale_1m_equals_oracle(codec, oracle, wl):
+    """the bench workload itself (bench.py: wl.room(1_000_000, seed=0)), byte for byte"""
+    check_oracle_parity(codec, oracle, wl, [wl.room(1_000_000, seed=0)])
+
+
 def test_c4_dense_body_rgb(codec, wl):
     frame = wl.body(800_000, seed=0)
     assert 300_000 < frame["points"].shape[0] <= 800_000
     check_roundtrip(codec, wl, [frame])
+
+
+def test_c4_dense_body_rgb_equals_oracle(codec, oracle, wl):
+    check_oracle_parity(codec, oracle, wl, [wl.body(800_000, seed=0)])
+
+
+def test_gop_of_two_large_frames_equals_oracle(codec, oracle, wl):
+    """two frames of 400k / 300k voxels in one GOP: batch offsets and per-frame top-k at sizes where every layer runs
+    its large-launch kernel"""
+    check_oracle_parity(codec, oracle, wl, [wl.room(400_000, seed=5), wl.body(300_000, seed=6)])
 
 
 def test_gop_with_ragged_frames(codec, wl):

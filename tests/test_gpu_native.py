@@ -301,3 +301,65 @@ def test_native_decode_survives_corrupted_containers(wl, codec):
             outcomes["error"] += 1
     assert outcomes["ok"] + outcomes["error"] == 40
     assert codec.decode(clean)[0].shape[0] == n_ref
+
+
+def _blob_offsets(container):
+    """byte offset of every frame's geometry blob inside a batched container (codec_parallel.py:173-216)"""
+    import struct
+    nf = struct.unpack_from(">i", container, 0)[0]
+    ly, lz = struct.unpack_from(">ii", container, 28)
+    pos, out = 36 + ly + lz, []
+    for _ in range(nf):
+        lp = struct.unpack_from(">i", container, pos)[0]
+        out.append(pos + 16)
+        pos += 16 + lp
+    return out
+
+
+def test_native_decode_refuses_a_moved_octree_origin(wl, codec):
+    """every bit of the 12 origin bytes of a geometry blob (octree_host.cpp: bytes 8..19, little-endian int32 x 3):
+    a flipped bit either leaves the root cube on its 2^depth grid (the cloud is translated; the decode succeeds with
+    the same point count) or takes it off the grid / out of range, and then the decoder must refuse the container
+    BEFORE the device path sizes its stride-16 / stride-32 sets from the octree's level counts"""
+    native = pkg("native")
+    frames = [wl.sphere_shell(20, 7.5, seed=4, offset=(-37, 5, 19)), wl.sphere_shell(16, 5.5, seed=5, offset=(40, 0, -8))]
+    coords, feats = _stack(frames)
+    cont, _, _ = codec.encode(coords, feats, 2, [[1, 1]])
+    clean = cont[0]
+    n_ref = codec.decode(clean)[0].shape[0]
+    refused = moved = 0
+    for off in _blob_offsets(clean):
+        depth = clean[off + 2]
+        for byte in range(8, 20):
+            for bit in range(8):
+                b = bytearray(clean)
+                b[off + byte] ^= 1 << bit
+                try:
+                    c, col, offs, _, _ = codec.decode(bytes(b))
+                    # only a translation by a multiple of the root cube's side can pass
+                    assert 8 * (byte % 4) + bit >= depth and c.shape[0] == n_ref
+                    moved += 1
+                except native.PccError as e:
+                    assert e.code in (-5, -3), e
+                    refused += 1
+    assert refused >= 2 * 3 * 3 and refused + moved == 2 * 96     # at least the low `depth` bits of every axis
+    assert codec.decode(clean)[0].shape[0] == n_ref
+
+
+def test_native_decode_refuses_announced_sizes_it_cannot_verify(wl, codec):
+    """a header that announces far more latent rows than the streams hold is refused without the decoder sizing
+    host or pinned buffers from the announcement"""
+    import struct
+    native = pkg("native")
+    coords, feats = _stack([wl.sphere_shell(20, 7.5, seed=4)])
+    cont, _, _ = codec.encode(coords, feats, 1, [[1, 1]])
+    clean = bytearray(cont[0])
+    off = _blob_offsets(bytes(clean))[0]
+    for n_y in (1 << 30, (1 << 27) + 1, 5_000_000):
+        b = bytearray(clean)
+        struct.pack_into(">i", b, 20, n_y)          # N_y of the container header
+        struct.pack_into(">i", b, 24, n_y)          # N_z <= N_y
+        struct.pack_into("<I", b, off + 4, n_y)     # and the blob's own point count
+        with pytest.raises(native.PccError):
+            codec.decode(bytes(b))
+    assert codec.decode(bytes(clean))[0].shape[0] == coords.shape[0]
