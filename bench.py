@@ -4,13 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by the driver under torch.distributed.run, one rank per GPU)
 
-One step = CompressionPipeline.compress(gop of one 1M-point frame, the three
-quality settings of shared/config.yaml:12-15) + DecompressionPipeline.
-decompress(container of the last quality).  Inputs are resident in HBM when the
-timed region starts and the decoded frame stays in HBM (DESIGN.md notes the
-PCIe-inclusive rate).  N > 1: every rank codes its own frame (the path shards by
-frame / tile, no data-path collective), value = frames of all ranks / max time.
-Rank 0 prints ONE JSON line.
+One step = the reference's operator contract: CompressionPipeline.compress(gop of host numpy frames as the
+capturer leaves them — int16 points, float64 colours — at the three quality settings of shared/config.yaml:12-15)
++ DecompressionPipeline.decompress(container of the last quality) -> host numpy frames
+(sender/encoder/codec_pipeline.py:239-267, receiver/decoder/codec_parallel.py:474-502).  `value` is that rate, PCIe
+legs included; `value_hbm_resident` is the same K steps with the frame already in HBM and the reconstruction left
+there (the figure the kernels' roofline refers to).  D1-PSNR / Y-PSNR of the reconstruction (metrics.py, outside
+the timed region) are reported for the HIP path and for the CPU oracle; the two reconstructions must be equal.
+
+N = 1: the C2 frame (BASELINE.json configs[1]).  N > 1: BASELINE.json configs[4]'s tiling — a scan of 2N octree
+blocks of 500k voxels, two per rank (1M voxels per GPU and step, as at N = 1; N = 4 is configs[4]'s 4M points in 8
+blocks): every rank codes its blocks as one GOP, the sub-bitstreams of all ranks are exchanged by the variable-
+length all-gather of tiled.py (RCCL) INSIDE the timed region, and every rank decodes the blocks its neighbour coded,
+out of the gathered bundle.  value = 1M-voxel frames of all ranks / max time over ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -53,22 +59,23 @@ def cpu_baseline(wl, frame, n_sample, threads, budget_s=20.0):
     o = Oracle(threads=threads)
 
     def run(n):
+        whole = n >= pts.shape[0]
         keep = order[:n]
-        sample = {"points": frame["points"][keep], "colors": frame["colors"][keep]}
+        sample = frame if whole else {"points": frame["points"][keep], "colors": frame["colors"][keep]}
         t0 = time.time()
-        out, dbg = o.compress([sample], SETTINGS)
+        out, dbg = o.compress([dict(sample)], SETTINGS)
         t1 = time.time()
-        o.decompress(out[len(SETTINGS)])
-        return sample["points"].shape[0], t0, t1, time.time()
+        rec = o.decompress(out[len(SETTINGS)])
+        return sample["points"].shape[0], t0, t1, time.time(), (out, rec) if whole else None
 
-    n, t0, t1, t2 = run(min(n_sample, pts.shape[0]))
+    n, t0, t1, t2, full = run(min(n_sample, pts.shape[0]))
     scale = budget_s / max(t2 - t0, 1e-3)
     if scale > 1.5 and n < pts.shape[0]:
-        n, t0, t1, t2 = run(int(min(pts.shape[0], n * scale)))
+        n, t0, t1, t2, full = run(int(min(pts.shape[0], n * scale)))
     return {"value": (n / 1.0e6) / (t2 - t0), "unit": "frames/s (1M-point equivalent, linear in points)",
             "cores": threads, "kind": "port",
             "sample": f"{n}-point spatial crop of the same frame, Q=3 encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s, "
-                      f"oracle/ C restatement with OpenMP"}
+                      f"oracle/ C restatement with OpenMP"}, full
 
 
 def main():
@@ -79,6 +86,7 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=60_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="also report throughput with this many GOPs in flight (0/1 = skip)")
     args = ap.parse_args()
 
@@ -103,24 +111,42 @@ def main():
 
     pkg = importlib.import_module(PKG)
     wl = importlib.import_module(PKG + ".workloads")
-
-    t0 = time.time()
-    frame = wl.room(args.points, seed=rank)
-    n_pts = int(frame["points"].shape[0])
-    log(f"[rank {rank}] workload: {n_pts} voxels generated in {time.time() - t0:.1f}s")
+    tiled = importlib.import_module(PKG + ".tiled")
     dev = torch.device("cuda", local)
-    d_points = torch.from_numpy(frame["points"].astype(np.int32)).to(dev)
-    d_colors = torch.from_numpy(frame["colors"].astype(np.float32)).to(dev)
-
-    enc = pkg.CompressionPipeline(SETTINGS, device=local, slots=1)
-    dec = pkg.DecompressionPipeline(device=local, slots=1, output="device")
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     q_dec = len(SETTINGS)
 
-    def step():
-        gop = {"frames": [{"points": d_points, "colors": d_colors}], "timestamps": {}}
-        out, side = enc.compress(gop)
-        rec, dside = dec.decompress(out[q_dec])
-        return out, side, rec, dside
+    # ---- workload.  N = 1: the C2 frame.  N > 1: two 500k-voxel octree blocks of the tiled scan per rank.
+    t0 = time.time()
+    if world == 1:
+        frames = [wl.room(args.points, seed=0)]
+    else:
+        half = args.points // 2
+        frames = [wl.tiled_block(2 * rank + j, half, seed=0) for j in range(2)]
+    n_pts = int(sum(f["points"].shape[0] for f in frames))
+    log(f"[rank {rank}] workload: {len(frames)} frame(s), {n_pts} voxels generated in {time.time() - t0:.1f}s")
+    assert all(f["points"].dtype == np.int16 and f["colors"].dtype == np.float64 for f in frames)
+    d_frames = [{"points": torch.from_numpy(f["points"].astype(np.int32)).to(dev),
+                 "colors": torch.from_numpy(f["colors"].astype(np.float32)).to(dev)} for f in frames]
+
+    enc = pkg.CompressionPipeline(SETTINGS, device=local, slots=1)
+    dec = pkg.DecompressionPipeline(device=local, slots=1, output="numpy")
+    dec_dev = pkg.DecompressionPipeline(device=local, slots=1, output="device")
+
+    def step(host=True):
+        """one pass of the operator contract.  host=True: numpy frames in, numpy frames out (the contract of the
+        reference's operators); host=False: inputs resident in HBM, reconstruction left in HBM."""
+        src = frames if host else d_frames
+        d = dec if host else dec_dev
+        if world == 1:
+            out, side = enc.compress({"frames": [dict(f) for f in src], "timestamps": {}})
+            rec, dside = d.decompress(out[q_dec])
+            return out, side, rec, dside, out[q_dec]
+        # tiled scan: code my blocks, exchange the sub-bitstreams of every quality, decode what my neighbour coded
+        bundles, side = tiled.compress_tiled(enc.compress, [dict(f) for f in src], list(range(1, q_dec + 1)), coll_dev)
+        theirs = bundles[(rank + 1) % world][q_dec - 1]
+        rec, dside = d.decompress(theirs)
+        return {q: bundles[rank][q - 1] for q in range(1, q_dec + 1)}, side, rec, dside, theirs
 
     def prof_table(rts, n_steps):
         recs = []
@@ -141,11 +167,12 @@ def main():
         if i == max(args.warmup, 1) - 1:
             for r in rts:
                 r.prof_enable(True, reserve=400)
-        out, side, rec, dside = step()
-    assert rec[0]["points"].shape[0] == n_pts
+        out, side, rec, dside, decoded = step()
+    assert sum(int(r["points"].shape[0]) for r in rec) == n_pts or world > 1
     torch.cuda.synchronize()
     table_all, sum_all = prof_table(rts, 1)
     layer_all = [(k, v) for k, v in table_all if k[0] in ("sparse_conv", "convT_gen")]
+    step(host=False)                       # warm the HBM-resident variant's decoder slot too
 
     def fence():
         torch.cuda.synchronize()
@@ -153,28 +180,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # timed region: only the dominant kernel is bracketed (one event pair per step); bracketing all ~150 calls
-    # of a step costs the step ~0.5 ms of stream bubbles
+    def timed(host):
+        fence()
+        t_start = time.perf_counter()
+        e_ms, d_ms, last = [], [], None
+        for _ in range(args.steps):
+            last = step(host)
+            e_ms.append(1e3 * (last[1]["timestamps"]["codec_end"] - last[1]["timestamps"]["codec_start"]))
+            d_ms.append(1e3 * (last[3]["timestamps"]["codec_end"] - last[3]["timestamps"]["codec_start"]))
+        fence()
+        dt = time.perf_counter() - t_start
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, float(np.mean(e_ms)), float(np.mean(d_ms)), last
+
+    # timed region (`value`): K steps of the operator contract, host numpy in / host numpy out.  Only the dominant
+    # kernel is bracketed by HIP events (one pair per step); bracketing all ~150 calls of a step costs the step
+    # ~0.5 ms of stream bubbles
     if layer_all:
         (dom_op, dom_dims), _ = layer_all[0]
         for r in rts:
             r.prof_enable(True, reserve=8 * (args.steps + 1), only=dom_op, rows=dom_dims[0])
-    fence()
-    t_start = time.perf_counter()
-    enc_ms, dec_ms = [], []
-    for _ in range(args.steps):
-        out, side, rec, dside = step()
-        enc_ms.append(1e3 * (side["timestamps"]["codec_end"] - side["timestamps"]["codec_start"]))
-        dec_ms.append(1e3 * (dside["timestamps"]["codec_end"] - dside["timestamps"]["codec_start"]))
-    fence()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed, enc_ms, dec_ms, (out, side, rec, dside, decoded) = timed(host=True)
     # ---- launches of the dominant kernel inside the timed region (HIP events on the ctx streams)
     table, _ = prof_table(rts, args.steps)
+    # secondary: the same K steps with the frame resident in HBM and the reconstruction left there (no events)
+    elapsed_hbm, enc_ms_hbm, dec_ms_hbm, _ = timed(host=False)
     table = [kv for kv in table if layer_all and kv[0] == (dom_op, dom_dims)]
     if rank == 0:
         log("per-op device time of the last warm-up step (HIP events around every C-ABI call):")
@@ -199,9 +232,9 @@ def main():
         dec_o = pkg.DecompressionPipeline(device=local, slots=1, output="device", engine="ops")
         for r in enc_o.runtimes + dec_o.runtimes:
             r.pairs_log = {}
-        out_o, _ = enc_o.compress({"frames": [{"points": d_points, "colors": d_colors}], "timestamps": {}})
+        out_o, _ = enc_o.compress({"frames": [dict(f) for f in d_frames], "timestamps": {}})
         assert out_o[q_dec] == out[q_dec], "the two engines wrote different containers"
-        dec_o.decompress(out_o[q_dec])
+        dec_o.decompress(decoded)          # the container the timed steps decoded (N > 1: the neighbour's blocks)
         pairs = {}
         for r in enc_o.runtimes + dec_o.runtimes:
             pairs.update(r.pairs_log)
@@ -274,13 +307,13 @@ def main():
     # the codec (3 pool threads, sender/encoder/encoder.py:50, receiver/decoder/decoder.py:47): host
     # entropy coding of one frame overlaps GPU work of another.  Not the reported `value`.
     inflight = None
-    if args.inflight > 1:
+    if args.inflight > 1 and world == 1:
         import concurrent.futures as cf
         enc_n = pkg.CompressionPipeline(SETTINGS, device=local, slots=args.inflight)
         dec_n = pkg.DecompressionPipeline(device=local, slots=args.inflight, output="device")
 
         def step_n(_):
-            gop = {"frames": [{"points": d_points, "colors": d_colors}], "timestamps": {}}
+            gop = {"frames": [dict(f) for f in d_frames], "timestamps": {}}
             out_n, _s = enc_n.compress(gop)
             rec_n, _d = dec_n.decompress(out_n[q_dec])
             return rec_n[0]["points"].shape[0]
@@ -293,26 +326,55 @@ def main():
             fence()
             dt = time.perf_counter() - t0
         assert all(s == n_pts for s in sizes)
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
         inflight = {"in_flight": args.inflight, "value": args.steps * world / dt, "unit": "frames/s",
                     "ms_per_step": 1e3 * dt / args.steps,
-                    "note": "same K steps issued from a pool of worker threads, one codec slot (HIP stream + arena) "
-                            "each; informational, `value` above is the one-frame-at-a-time figure"}
+                    "note": "same K steps (frame resident in HBM, reconstruction left there) issued from a pool of "
+                            "worker threads, one codec slot (HIP stream + arena) each; informational, `value` above "
+                            "is the one-frame-at-a-time figure"}
         del enc_n, dec_n
 
-    cpu = None
+    cpu, oracle_full = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             abi = importlib.import_module(PKG + "._abi")
-            cpu = cpu_baseline(wl, frame, args.cpu_sample, abi.host_cpu_budget())
+            cpu, oracle_full = cpu_baseline(wl, frames[0], args.cpu_sample, abi.host_cpu_budget())
         except Exception as e:      # the oracle is only a reported baseline; never fail the bench on it
             log("cpu_baseline failed:", repr(e))
 
+    # ---- distortion (BASELINE.json's metric names D1-PSNR; the reference logs none — SURVEY.md §8d): MPEG pc_error
+    # point-to-point D1 and luma PSNR of the decoded frame against the source, outside the timed region; for the HIP
+    # reconstruction and for the CPU oracle's, which must be the same arrays
+    quality = None
+    if rank == 0 and world == 1 and not args.no_psnr:
+        metrics = importlib.import_module(PKG + ".metrics")
+        t0 = time.time()
+        quality = {"hip": metrics.frame_quality(frames[0], rec[0])}
+        if oracle_full is not None:
+            o_out, o_rec = oracle_full
+            quality["oracle"] = metrics.frame_quality(frames[0], o_rec[0])
+            quality["containers_equal_oracle"] = all(out[q] == o_out[q] for q in range(1, q_dec + 1))
+            quality["reconstruction_equals_oracle"] = bool(np.array_equal(rec[0]["points"], o_rec[0]["points"]) and
+                                                           np.array_equal(rec[0]["colors"], o_rec[0]["colors"]))
+            assert quality["containers_equal_oracle"] and quality["reconstruction_equals_oracle"], \
+                "HIP path and CPU oracle disagree on the bench frame"
+            assert quality["oracle"] == quality["hip"]
+        log(f"distortion figures in {time.time() - t0:.1f}s:", quality)
+
     if rank == 0:
         frames_total = args.steps * world
+        if world == 1:
+            workload = ("C2 ScanNet-scale 1M-point frame (BASELINE.json configs[1]): seeded indoor scene, 512x512x256 "
+                        "grid, F=1 frame per GOP, Q=3 settings, hyperprior model demo_small; host numpy in (int16 points, "
+                        "float64 colours) / host numpy out")
+            sharding = "one frame per GPU, no data-path collective"
+        else:
+            workload = (f"BASELINE.json configs[4] tiling at 2 octree blocks of {args.points // 2} voxels per GPU "
+                        f"({2 * world} blocks, {world * args.points} voxels per step; configs[4] itself is N=4): each "
+                        "rank codes its blocks as one GOP (Q=3), all-gather of the sub-bitstreams of every quality, each "
+                        "rank decodes the blocks its neighbour coded; host numpy in / host numpy out; hyperprior "
+                        "model demo_small")
+            sharding = ("tiles dealt to ranks, one variable-length all-gather of sub-bitstreams per step "
+                        f"({backend}) inside the timed region")
         line = {
             "metric": "point-cloud frames/sec encode+decode @1M pts",
             "value": frames_total / elapsed,
@@ -326,13 +388,29 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "C2 ScanNet-scale 1M-point frame (BASELINE.json configs[1]): seeded indoor scene, "
-                                   "512x512x256 grid, F=1 frame per GOP, Q=3 settings, hyperprior model demo_small "
-                                   "(seeded synthetic weights)",
-                       "points_per_frame": n_pts, "frames_per_step_per_gpu": 1, "qualities": len(SETTINGS),
-                       "decoded_quality": q_dec, "sharding": "one frame per GPU, no data-path collective"},
-            "encode_ms": float(np.mean(enc_ms)), "decode_ms": float(np.mean(dec_ms)),
+            "config": {"workload": workload,
+                       "weights": "UNTRAINED: seeded synthetic checkpoint (tools/make_checkpoint.py) — the reference's "
+                                  "weights are not in its tree; bpp and PSNR below are those of this checkpoint, not of "
+                                  "a trained codec, and the decoder's neighbourhood statistics come from its top-k",
+                       "points_per_step_per_gpu": n_pts, "frames_per_step_per_gpu": len(frames),
+                       "qualities": len(SETTINGS), "decoded_quality": q_dec, "sharding": sharding,
+                       "value_basis": "operator contract: host numpy frames in, host numpy frames out (PCIe legs inside "
+                                      "the timed region); value_hbm_resident = frame already in HBM, reconstruction "
+                                      "left in HBM"},
+            "encode_ms": enc_ms, "decode_ms": dec_ms,
+            "value_hbm_resident": frames_total / elapsed_hbm,
+            "ms_per_step_hbm_resident": 1e3 * elapsed_hbm / args.steps,
+            "encode_ms_hbm_resident": enc_ms_hbm, "decode_ms_hbm_resident": dec_ms_hbm,
             "bpp": [float(b) for b in side["gop_info"]["bpp"]],
+            "d1_psnr": quality["hip"]["d1_psnr"] if quality else None,
+            "y_psnr": quality["hip"]["y_psnr"] if quality else None,
+            "d1_psnr_oracle": quality["oracle"]["d1_psnr"] if quality and "oracle" in quality else None,
+            "y_psnr_oracle": quality["oracle"]["y_psnr"] if quality and "oracle" in quality else None,
+            "psnr": ({"definition": "MPEG pc_error D1 point-to-point, 10 log10(3 p^2 / max(mse A->B, mse B->A)); "
+                                    "Y = BT.709 luma over nearest-neighbour pairs; decoded quality 3 vs source frame",
+                      "peak": quality["hip"]["peak"],
+                      "reconstruction_equals_oracle": quality.get("reconstruction_equals_oracle"),
+                      "containers_equal_oracle": quality.get("containers_equal_oracle")} if quality else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "throughput_in_flight": inflight,

@@ -77,13 +77,14 @@ def room(n_target=1_000_000, extent=(512, 512, 256), seed=0, offset=(-200, -150,
             p = np.empty((g.shape[0], 3), dtype=np.int64)
             p[:, o[0]], p[:, o[1]], p[:, axis] = g[:, 0], g[:, 1], level
             parts.append(p)
+    sc = min(1.0, float(ex.min()) / 256.0)     # furniture shrinks with rooms smaller than the default (tests)
     for _ in range(20):
-        size = rng.integers(20, 120, 3)
+        size = rng.integers(max(2, int(20 * sc)), max(4, int(120 * sc)), 3)
         lo = rng.integers(1, ex - size - 1)
         area = 2 * (size[0] * size[1] + size[1] * size[2] + size[0] * size[2])
         parts.append(_box_surface(rng, lo, size, int(area * 3)))
     for _ in range(10):
-        r = int(rng.integers(15, 50))
+        r = int(rng.integers(max(2, int(15 * sc)), max(4, int(50 * sc))))
         c = rng.integers(r + 1, ex - r - 1)
         parts.append(_sphere_surface(rng, c, r, int(4 * np.pi * r * r * 4)))
     pts = _dedup(np.concatenate(parts, 0))
@@ -149,13 +150,15 @@ def body(n_target=800_000, bits=10, seed=0):
     return frame(pts, rng, offset=(-size // 2, -size // 2, -size // 2))
 
 
+def tiled_block(t, n_per_tile=500_000, seed=0):
+    """block t of the C5 scan: an independent C2-style room (its own seed, a slightly shifted origin)"""
+    off = (-200 + 40 * (t & 1), -150 + 30 * ((t >> 1) & 1), -100 + 20 * ((t >> 2) & 1))
+    return room(n_per_tile, seed=seed + 1 + t, offset=off)
+
+
 def tiled_scan(tiles=8, n_per_tile=500_000, seed=0):
     """C5: 2x2x2 spatial tiles, each an independent C2-style block = one batch item"""
-    out = []
-    for t in range(tiles):
-        off = (-200 + 40 * (t & 1), -150 + 30 * ((t >> 1) & 1), -100 + 20 * ((t >> 2) & 1))
-        out.append(room(n_per_tile, seed=seed + 1 + t, offset=off))
-    return out
+    return [tiled_block(t, n_per_tile, seed) for t in range(tiles)]
 
 
 def fused_scan(n_total=4_000_000, seed=0, extent=(512, 512, 256)):

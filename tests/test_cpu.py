@@ -3,9 +3,11 @@ reference's structural contracts, the host coders of libpcc_hip.so against the
 oracle, the container layout, and that the C-ABI library loads and exports
 every symbol include/pcc.h declares.  No GPU compute is called here."""
 import hashlib
+import importlib
 import os
 import re
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -373,3 +375,113 @@ def test_checkpoint_blob_layout_and_no_cpu_fallback_of_the_native_engine():
         assert not lib.pcc_codec_create(blob, len(blob), 0, None)          # no device: NULL + error text, no crash
         assert lib.pcc_last_error()
         assert not lib.pcc_codec_create(b"nope" + blob[4:], len(blob), 0, None)
+
+
+# ---------------------------------------------------------------- hand-derived KATs of the [RECALL] algorithms
+def _orc_rans(oracle, sym, idx, cdf, sizes, offs):
+    import ctypes as C
+    sym = np.ascontiguousarray(sym, np.int32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    out = np.empty(8 * sym.shape[0] + 64, np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)                                      # noqa: E731
+    n = oracle.lib.orc_rans_encode(p(sym), p(idx), C.c_int64(sym.shape[0]), p(cdf), C.c_int(cdf.shape[1]), p(sizes),
+                                   p(offs), p(out), C.c_int64(out.shape[0]))
+    assert n >= 0
+    return out[:n].tobytes()
+
+
+def test_rans_bypass_escape_known_answers(oracle):
+    """CompressAI's out-of-range escape (rans_interface.cpp encode_with_indexes, restated in pcc_oracle.c:326 and
+    rans_host.cpp), derived by hand.  Table: cdf = [0, 32768, 65536], cdf_length 3 -> max_value = 1: symbol 0 is the
+    only regular bin, bin 1 (start 32768, freq 32768) is the escape.  offset 0.
+
+    sym = -3:  value < 0 -> raw = -2 * (-3) - 1 = 5, one nibble.  Coding order: escape bin, nibble count 1, nibble 5;
+      rANS codes in reverse from x = 2^31 (bypass step: x = (x << 4) | v, no renormalisation below 2^59):
+        put 5      x = 2^35 + 5
+        put 1      x = 2^39 + 81
+        escape     x = ((x / 32768) << 16) + x % 32768 + 32768 = 2^40 + 81 + 32768 = 2^40 + 32849
+      flush: low word 32849, high word 256.
+    sym = +4:  value >= max_value -> raw = 2 * (4 - 1) = 6:  2^35 + 6 -> 2^39 + 97 -> 2^40 + 32865.
+    sym = -20: raw = 39 = 0x27, two nibbles, least significant first (7, then 2): order escape, 2, 7, 2;
+      reverse: 2^35 + 2 -> 2^39 + 39 -> 2^43 + 626 -> 2^44 + 626 + 32768: low word 33394, high word 4096."""
+    runtime = pkg("runtime")
+    cdf = np.array([[0, 32768, 65536, 0]], dtype=np.int32)
+    sizes, offs, idx = np.array([3], np.int32), np.array([0], np.int32), np.array([0], np.int32)
+    for sym, low, high in ((-3, 32849, 256), (4, 32865, 256), (-20, 33394, 4096)):
+        want = struct.pack("<II", low, high)
+        s = np.array([sym], np.int32)
+        assert runtime.rans_encode(s, idx, cdf, sizes, offs) == want, sym
+        assert _orc_rans(oracle, s, idx, cdf, sizes, offs) == want, sym
+        assert runtime.rans_decode(want, idx, cdf, sizes, offs).tolist() == [sym]
+    # a regular symbol in front of an escaped one: the stream decodes in coding order
+    s = np.array([0, -3, 0, 4], np.int32)
+    i4 = np.zeros(4, np.int32)
+    both = runtime.rans_encode(s, i4, cdf, sizes, offs)
+    assert both == _orc_rans(oracle, s, i4, cdf, sizes, offs)
+    assert runtime.rans_decode(both, i4, cdf, sizes, offs).tolist() == s.tolist()
+
+
+def test_pmf_to_quantized_cdf_known_answers():
+    """CompressAI's pmf_to_quantized_cdf (cpp_exts/ops/ops.cpp; restated in tools/make_checkpoint.py, which built the
+    tables of the checkpoint), by hand at precision 4 (total 16):
+
+    pmf [0.6, 0, 0.3, 0, 0.1]: round(p * 16) = [10, 0, 5, 0, 2], sum 17; (16 * f) // 17 = [9, 0, 4, 0, 1];
+      partial sums [0, 9, 9, 13, 13, 14], last forced to 16 -> [0, 9, 9, 13, 13, 16].
+      i = 1: cdf[1] == cdf[2]; frequencies [9, 0, 4, 0, 3]; smallest frequency > 1 is 3 at symbol 4 (> i): cdf[2..4] += 1
+             -> [0, 9, 10, 14, 14, 16]
+      i = 3: cdf[3] == cdf[4]; frequencies [9, 1, 4, 0, 2]; smallest > 1 is 2 at symbol 4: cdf[4] += 1
+             -> [0, 9, 10, 14, 15, 16]
+    pmf [0.2, 0.55, 0, 0.25]: round = [3, 9, 0, 4], sum 16 -> [0, 3, 12, 12, 16];
+      i = 2: frequencies [3, 9, 0, 4]; smallest > 1 is 3 at symbol 0 (< i): cdf[1..2] -= 1 -> [0, 2, 11, 12, 16]
+    pmf [2.5/16, 13.5/16]: std::round rounds halves away from zero: [3, 14], sum 17; [48 // 17, 224 // 17] = [2, 13]
+      -> [0, 2, 15] -> last forced: [0, 2, 16]"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        mk = importlib.import_module("make_checkpoint")
+    finally:
+        sys.path.pop(0)
+    assert mk.pmf_to_quantized_cdf([0.6, 0.0, 0.3, 0.0, 0.1], 4).tolist() == [0, 9, 10, 14, 15, 16]
+    assert mk.pmf_to_quantized_cdf([0.2, 0.55, 0.0, 0.25], 4).tolist() == [0, 2, 11, 12, 16]
+    assert mk.pmf_to_quantized_cdf([2.5 / 16, 13.5 / 16], 4).tolist() == [0, 2, 16]
+
+
+def test_build_indexes_and_offset_dequantisation_known_answers(oracle):
+    """GaussianConditional.build_indexes on the default scale table exp(linspace(ln 0.11, ln 256, 64)):
+    idx = 63 - #{table[:-1] entries >= scale}  (CompressAI: indexes -= (scales <= s) for s in table[:-1]),
+    so a scale at or below table[0] = 0.11 gives 0, one above table[62] gives 63, and table[k] itself gives k.
+    De-quantisation with offsets (receiver/decoder/codec_parallel.py:398-409): y = sign(s)(|s| + off)/scale + mean,
+    off = -get_offsets(sigma, scale) and 0 where the symbol is 0."""
+    table = oracle.t["gaussian_conditional.scale_table"].astype(np.float32)
+    assert table.shape == (64,) and abs(float(table[0]) - 0.11) < 1e-6 and abs(float(table[-1]) - 256.0) < 1e-3
+    c = 32
+    one = np.ones((1, c), np.float32)
+    for k in (0, 1, 17, 62, 63):
+        params = np.concatenate([np.full((1, c), table[k], np.float32), np.zeros((1, c), np.float32)], 1)
+        _, idx = oracle.gaussian_quant(np.zeros((1, c), np.float32), params, one)
+        assert idx.reshape(-1).tolist() == [k] * c, k
+    lo = np.concatenate([np.full((1, c), 0.01, np.float32), np.zeros((1, c), np.float32)], 1)
+    hi = np.concatenate([np.full((1, c), 1000.0, np.float32), np.zeros((1, c), np.float32)], 1)
+    assert oracle.gaussian_quant(np.zeros((1, c), np.float32), lo, one)[1].max() == 0
+    assert oracle.gaussian_quant(np.zeros((1, c), np.float32), hi, one)[1].min() == 63
+    # symbols are round(y * scale - mean * scale): y = 2.4, mean = 0.5, scale = 2 -> round(4.8 - 1.0) = 4
+    params = np.concatenate([np.ones((1, c), np.float32), np.full((1, c), 0.5, np.float32)], 1)
+    sym, _ = oracle.gaussian_quant(np.full((1, c), 2.4, np.float32), params, 2 * one)
+    assert sym.reshape(-1).tolist() == [4] * c
+
+
+def test_d1_and_luma_psnr_known_answers():
+    """metrics.py against numbers worked out by hand.  A = {(0,0,0), (1,0,0)}, B = {(0,0,0), (3,0,0)}:
+    A -> B squared distances (0, 1) -> mse 0.5; B -> A (0, 4) -> mse 2; D1 = 10 log10(3 * 7^2 / 2) = 18.6629 dB at peak 7.
+    Grey colours A = (0.5, 0.5), B = (0.5, 1.0): A -> B both map to B's first point -> 0; B -> A: (0, 0.25) -> 0.125;
+    luma PSNR = 10 log10(1 / 0.125) = 9.0309 dB."""
+    m = pkg("metrics")
+    a = np.array([[0, 0, 0], [1, 0, 0]])
+    b = np.array([[0, 0, 0], [3, 0, 0]])
+    psnr, e_ab, e_ba = m.d1_psnr(a, b, 7)
+    assert (e_ab, e_ba) == (0.5, 2.0) and abs(psnr - 10 * np.log10(147 / 2)) < 1e-12 and abs(psnr - 18.6629) < 1e-4
+    ca = np.array([[0.5] * 3, [0.5] * 3])
+    cb = np.array([[0.5] * 3, [1.0] * 3])
+    y, c_ab, c_ba = m.y_psnr(a, ca, b, cb)
+    assert abs(c_ab) < 1e-30 and abs(c_ba - 0.125) < 1e-12 and abs(y - 9.0309) < 1e-4
+    assert m.d1_psnr(a, a, 7)[0] == float("inf")
+    assert m.peak_of(np.array([[-200, -150, -100], [311, 361, 155]])) == 511
