@@ -12,11 +12,12 @@ legs included; `value_hbm_resident` is the same K steps with the frame already i
 there (the figure the kernels' roofline refers to).  D1-PSNR / Y-PSNR of the reconstruction (metrics.py, outside
 the timed region) are reported for the HIP path and for the CPU oracle; the two reconstructions must be equal.
 
-N = 1: the C2 frame (BASELINE.json configs[1]).  N > 1: BASELINE.json configs[4]'s tiling — a scan of 2N octree
-blocks of 500k voxels, two per rank (1M voxels per GPU and step, as at N = 1; N = 4 is configs[4]'s 4M points in 8
-blocks): every rank codes its blocks as one GOP, the sub-bitstreams of all ranks are exchanged by the variable-
-length all-gather of tiled.py (RCCL) INSIDE the timed region, and every rank decodes the blocks its neighbour coded,
-out of the gathered bundle.  value = 1M-voxel frames of all ranks / max time over ranks.  Rank 0 prints ONE JSON line.
+N = 1: the C2 frame (BASELINE.json configs[1]).  N > 1: BASELINE.json configs[4]'s tiling — a fused scan of N C2
+rooms side by side (N x 1M voxels), cut into 2N octree blocks of 256 x 512 x 256 voxels (tiled.cut_tiles), two per
+rank: the same 1M voxels per GPU and step as at N = 1, and N = 4 is configs[4] itself (4M points in 8 blocks).
+Every rank codes its two blocks as one GOP, the sub-bitstreams of all ranks are exchanged by the variable-length
+all-gather of tiled.py (RCCL) INSIDE the timed region, and every rank decodes the blocks its neighbour coded, out of
+the gathered bundle.  value = 1M-voxel frames of all ranks / max time over ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -121,8 +122,10 @@ def main():
     if world == 1:
         frames = [wl.room(args.points, seed=0)]
     else:
-        half = args.points // 2
-        frames = [wl.tiled_block(2 * rank + j, half, seed=0) for j in range(2)]
+        # room `rank` of a fused scan of `world` C2 rooms side by side along x, cut into its two octree blocks
+        room = wl.room(args.points, seed=rank, offset=(512 * rank - 256 * world, -512, -256))
+        frames, origins = tiled.cut_tiles(room, (256, 512, 256))
+        assert len(frames) == 2, origins
     n_pts = int(sum(f["points"].shape[0] for f in frames))
     log(f"[rank {rank}] workload: {len(frames)} frame(s), {n_pts} voxels generated in {time.time() - t0:.1f}s")
     assert all(f["points"].dtype == np.int16 and f["colors"].dtype == np.float64 for f in frames)
@@ -368,11 +371,11 @@ def main():
                         "float64 colours) / host numpy out")
             sharding = "one frame per GPU, no data-path collective"
         else:
-            workload = (f"BASELINE.json configs[4] tiling at 2 octree blocks of {args.points // 2} voxels per GPU "
-                        f"({2 * world} blocks, {world * args.points} voxels per step; configs[4] itself is N=4): each "
-                        "rank codes its blocks as one GOP (Q=3), all-gather of the sub-bitstreams of every quality, each "
-                        "rank decodes the blocks its neighbour coded; host numpy in / host numpy out; hyperprior "
-                        "model demo_small")
+            workload = (f"BASELINE.json configs[4] tiling: fused scan of {world} C2 rooms ({world * args.points} voxels) "
+                        f"cut into {2 * world} octree blocks of 256x512x256, two blocks ({args.points} voxels) per GPU "
+                        "(configs[4] itself is N=4: 4M points, 8 blocks): each rank codes its blocks as one GOP (Q=3), "
+                        "all-gather of the sub-bitstreams of every quality, each rank decodes the blocks its neighbour "
+                        "coded; host numpy in / host numpy out; hyperprior model demo_small")
             sharding = ("tiles dealt to ranks, one variable-length all-gather of sub-bitstreams per step "
                         f"({backend}) inside the timed region")
         line = {
