@@ -280,6 +280,7 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_mfma_pipe(
 }
 
 #include "conv_compact.h"
+#include "conv16.h"
 
 // scalar-fmaf reference path on the GPU (any cin/cout), same bits as the MFMA path
 __global__ __launch_bounds__(256) void k_gconv_scalar(
@@ -601,6 +602,24 @@ extern "C" int pcc_sparse_conv_head_up(pcc_ctx* ctx, const float* d_in, int64_t 
               "PCC_CONV_SIMPLE / PCC_CONV_COMPACT=0 / PCC_CONV_UP=0 select the explicit rule book: pcc_derive_map_up)");
   const int64_t n_out = 8 * n_parents;
   PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
+  static const int conv16 = [] { const char* e = getenv("PCC_CONV16"); return e ? atoi(e) : 0; }();
+  if (conv16) {
+    pcc_arena_reset(ctx);
+    PCC_TRY(pcc_arena_reserve(ctx, 27 * 1024 * 4 + 512));
+    float* wsw = (float*)pcc_arena_alloc(ctx, 27 * 1024 * 4);
+    if (!wsw) return PCC_E_NOMEM;
+    hipLaunchKernelGGL(k_conv16_swizzle, dim3(27 * 4), dim3(256), 0, ctx->stream, d_w, 27, wsw);
+    if (conv16 == 2)
+      hipLaunchKernelGGL((k_gconv16<true, true, true>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0, ctx->stream,
+                         d_in, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out, d_head_w, d_head_b,
+                         d_head_out);
+    else
+      hipLaunchKernelGGL((k_gconv16<true, true, false>), dim3((nblk(n_out, 64) + 7) / 8 * 8), dim3(64), 0, ctx->stream,
+                         d_in, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out, d_head_w, d_head_b,
+                         d_head_out);
+    PCC_CHECK_LAUNCH();
+    return PCC_OK;
+  }
   if (conv_w4(n_out))
     hipLaunchKernelGGL((k_gconv_mfma_compact_w4<true, true>), dim3((nblk(n_out, 256) + 7) / 8 * 8), dim3(256), 0,
                        ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, d_w, d_bias, relu, d_out, d_head_w,
@@ -682,3 +701,11 @@ extern "C" int pcc_linear_gather(pcc_ctx* ctx, const float* d_in, const uint32_t
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }
+
+#if PCC_CONV_STAMP
+// diagnostic builds only: the per-wave phase sums of the last k_gconv_mfma_compact_w4<.., UP> launch
+extern "C" int pcc_debug_stamps(unsigned long long* h_out, int n) {
+  if (n > 4096 * PCC_NSTAMP) n = 4096 * PCC_NSTAMP;
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(pcc_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : -2;
+}
+#endif

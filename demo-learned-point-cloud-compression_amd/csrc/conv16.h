@@ -1,0 +1,259 @@
+// conv16.h — row-compacting 32 -> 32 gather-convolution on 16-slot items (included by conv.hip).
+//
+// Same arithmetic as conv_compact.h (out = bias; for k ascending over PRESENT neighbours, ci ascending:
+// out = fmaf(x, w, out); v_mfma_f32_16x16x4_f32 is that chain four ci at a time), different shape of the work:
+//
+//   * the rows of a 64-row window that have offset k are packed into ITEMS of 16 slots (not groups of 32): a partly
+//     filled item wastes at most 15 slots instead of 31 — issued / useful matrix work on bench.py's dominant layer
+//     1.18 instead of 1.38 (simulated on its geometry and counted by SQ_INSTS_MFMA);
+//   * an item is two independent chains of 8 v_mfma_f32_16x16x4_f32 (output channels 0..15 and 16..31) issued
+//     alternately: the 40-cycle dependent latency of one chain hides behind the other chain's 32-cycle issue;
+//   * one wave per workgroup and no workgroup barrier: a wave reads the weights of an offset as its MFMA operands
+//     straight from a pre-swizzled copy (pcc_conv16_swizzle: [k][lane][16] floats — four coalesced dwordx4 per
+//     lane and offset instead of sixteen dword loads), so waves never wait for each other;
+//   * nothing is waited for right after it is issued.  In the stamped build of k_gconv_mfma_compact_w4
+//     (tools/stamp_conv.py) a wave spent 17 % of its time waiting for the neighbour index it had just asked for,
+//     16 % in the per-offset barrier, 10 % in the two dependent LDS round trips slot -> row -> accumulator and 12 %
+//     around the slot-list read in front of the gathers, against 31 % in its matrix chains.  Here the neighbour index
+//     of offset k+2 is only CONSUMED one step later (the child-index arithmetic of the UP form is deferred to the
+//     compaction), the slot records of offset k+1 (input row, accumulator row) are read into registers right after
+//     the compaction, the gathered rows of offset k+1's item g are requested into the registers item g of offset k
+//     has just been consumed from (a whole offset of prefetch distance on ONE register set), and the accumulator
+//     tile of item g+1 is read while the chains of item g run (items of one offset touch disjoint rows).
+//
+// Lane (n, q) = (lane & 15, lane >> 4).  MFMA operands (D = A x B, A = W^T block 16 co x 4 ci, B = x^T block 4 ci x
+// 16 slots): A lane (m, q) holds W[4s + q][m (+16)], B lane (n, q) holds x[slot n][4s + q], D lane (n, q) holds
+// channels 4q .. 4q+3 (+16) of slot n — a row's accumulator is two 16-B pieces at row * AP + 4q and + 16.
+//
+// PERM: the input rows are stored channel-permuted, position 8q + s holding channel 4s + q: lane (n, q) reads its
+// eight B operands with two dwordx4 and no shaping.  The native decoder stores the output of the generative up
+// stages that way (permuted weight columns, codec.hip).  Natural layout (PERM = false): lane (n, q) reads channels
+// 8q .. 8q+7 and the four q-lanes of a slot transpose two 4 x 4 blocks with v_permlane32_swap / v_permlane16_swap.
+#pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PCC16_SYNC()                                         \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+// weights [k_vol][32][32] (ci major) -> [k_vol][64 lanes][16]: lane (m, q): s = 0..7: W[4s+q][m], then W[4s+q][16+m]
+__global__ __launch_bounds__(256) void k_conv16_swizzle(const float* __restrict__ w, int k_vol, float* __restrict__ wsw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k_vol * 1024) return;
+  const int k = t >> 10, l = (t >> 4) & 63, e = t & 15;
+  const int m = l & 15, q = l >> 4, s = e & 7, hi = e >> 3;
+  wsw[t] = w[(k * 32 + 4 * s + q) * 32 + 16 * hi + m];
+}
+
+template <bool HEAD, bool UP, bool PERM>
+__global__ __launch_bounds__(64) void k_gconv16(
+    const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
+    int64_t n_out, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
+    float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
+    float* __restrict__ head_out) {
+  constexpr int R = 64;    // rows of the window
+  constexpr int AP = 36;   // accumulator row pitch (floats)
+  constexpr int NI = 4;    // items an offset can have
+  __shared__ __attribute__((aligned(16))) float acc_lds[(R + 1) * AP];   // row R = sink of the pad slots
+  __shared__ __attribute__((aligned(8))) int2 rec[2][R];                 // slot -> (input row, accumulator row)
+
+  const int lane = threadIdx.x;
+  // XCD-aware window order (conv_compact.h): every XCD walks one contiguous eighth of the Morton-sorted rows
+  const int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t row0 = window * R;
+  if (row0 >= n_out) return;
+  const int n = lane & 15, q = lane >> 4;
+  const int grow = lane >> 3, chunk = lane & 7;
+
+  {  // accumulators start at the bias
+    const float* bp = bias + chunk * 4;
+    const float4 b4 = make_float4(bp[0], bp[1], bp[2], bp[3]);
+#pragma unroll
+    for (int it = 0; it < R / 8; ++it)
+      *reinterpret_cast<float4*>(&acc_lds[(it * 8 + grow) * AP + chunk * 4]) = b4;
+    if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[R * AP + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- neighbour index of this lane's row: requested two offsets ahead, turned into a row one offset later
+  const int64_t r_own = row0 + lane;
+  const bool row_ok = r_own < n_out;
+  const int64_t rc = row_ok ? r_own : n_out - 1;
+  int32_t nb_raw = -1;   // UP: row of the parent-level neighbour; else the neighbour row itself
+  int nb_op = 0;         // UP: octant of the neighbour inside that parent
+  bool nb_live = false;  // offset exists and the lane owns a row
+  auto request_nb = [&](int k) {
+    const int kk = k < k_vol ? k : k_vol - 1;
+    nb_live = k < k_vol && row_ok;
+    if constexpr (UP) {
+      const int o = (int)(rc & 7);
+      const int tx = ((o >> 2) & 1) + (kk / 9) - 1, ty = ((o >> 1) & 1) + ((kk / 3) % 3) - 1, tz = (o & 1) + (kk % 3) - 1;
+      const int kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
+      nb_op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+      nb_raw = nbr[(int64_t)kp * pitch + (rc >> 3)];
+    } else {
+      nb_raw = nbr[(int64_t)kk * pitch + rc];
+    }
+  };
+  // pack the rows that have the requested offset into slot records `b`; returns their count
+  auto compact = [&](int b) -> int {
+    const bool p = nb_live && nb_raw >= 0;
+    const int32_t src = UP ? ((nb_raw << 3) | nb_op) : nb_raw;
+    const unsigned long long bal = __ballot(p);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    const int cnt = __popcll(bal);
+    if (p) rec[b][rank] = make_int2(src, lane * (AP * 4));
+    const int sl = cnt + lane;   // every remaining slot is a pad: row 0 of `in`, accumulated into the sink row
+    if (sl < R) rec[b][sl] = make_int2(0, R * (AP * 4));
+    return cnt;
+  };
+
+  float4 G[NI][2];              // gathered rows (B operands) of the items of one offset
+  float4 Wc[4], Wn[4];          // A operands of the current / next offset
+  int rin[NI], racc_c[NI], racc_n[NI];
+  auto load_w = [&](float4 (&W)[4], int k) {
+    const int kk = k < k_vol ? k : k_vol - 1;
+    const float4* p = reinterpret_cast<const float4*>(wsw + ((int64_t)kk * 64 + lane) * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[j] = p[j];
+  };
+  auto read_records = [&](int b) {
+#pragma unroll
+    for (int g = 0; g < NI; ++g) {
+      const int2 r = rec[b][g * 16 + n];
+      rin[g] = r.x;
+      racc_n[g] = r.y;
+    }
+  };
+  auto gather = [&](int g) {
+    const float* xr = in + (int64_t)rin[g] * 32 + q * 8;
+    G[g][0] = *reinterpret_cast<const float4*>(xr);
+    G[g][1] = *reinterpret_cast<const float4*>(xr + 4);
+  };
+  auto acc_read = [&](int byte_off, f32x4& lo, f32x4& hi) {
+    const char* base = reinterpret_cast<const char*>(acc_lds) + byte_off + q * 16;
+    const float4 a = *reinterpret_cast<const float4*>(base);
+    const float4 b = *reinterpret_cast<const float4*>(base + 64);
+    lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w;
+    hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; hi[3] = b.w;
+  };
+  auto acc_write = [&](int byte_off, const f32x4& lo, const f32x4& hi) {
+    char* base = reinterpret_cast<char*>(acc_lds) + byte_off + q * 16;
+    *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<float4*>(base + 64) = make_float4(hi[0], hi[1], hi[2], hi[3]);
+  };
+  auto contract = [&](int g, f32x4& lo, f32x4& hi) {
+    float xv[8];
+    if constexpr (PERM) {
+      xv[0] = G[g][0].x; xv[1] = G[g][0].y; xv[2] = G[g][0].z; xv[3] = G[g][0].w;
+      xv[4] = G[g][1].x; xv[5] = G[g][1].y; xv[6] = G[g][1].z; xv[7] = G[g][1].w;
+    } else {
+      // lane (n, t) holds channels 8t + e: xv[2t'] of lane q must become channel 8t' + q, xv[2t'+1] channel 8t' + 4 + q:
+      // transpose the 4 x 4 blocks (lane t, element e) of the low and of the high four elements
+      unsigned m[2][4] = {{__float_as_uint(G[g][0].x), __float_as_uint(G[g][0].y), __float_as_uint(G[g][0].z), __float_as_uint(G[g][0].w)},
+                          {__float_as_uint(G[g][1].x), __float_as_uint(G[g][1].y), __float_as_uint(G[g][1].z), __float_as_uint(G[g][1].w)}};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x2 p = __builtin_amdgcn_permlane32_swap(m[b][0], m[b][2], false, false);
+        m[b][0] = p[0]; m[b][2] = p[1];
+        p = __builtin_amdgcn_permlane32_swap(m[b][1], m[b][3], false, false);
+        m[b][1] = p[0]; m[b][3] = p[1];
+        p = __builtin_amdgcn_permlane16_swap(m[b][0], m[b][1], false, false);
+        m[b][0] = p[0]; m[b][1] = p[1];
+        p = __builtin_amdgcn_permlane16_swap(m[b][2], m[b][3], false, false);
+        m[b][2] = p[0]; m[b][3] = p[1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xv[2 * t + b] = __uint_as_float(m[b][t]);
+      }
+    }
+    const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
+    const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: offset 0 compacted and gathered, offset 1 requested
+  request_nb(0);
+  int cnt_cur = compact(0);
+  request_nb(1);
+  load_w(Wc, 0);
+  PCC16_SYNC();
+  read_records(0);
+#pragma unroll
+  for (int g = 0; g < NI; ++g) {
+    racc_c[g] = racc_n[g];
+    gather(g);
+  }
+
+  for (int k = 0; k < k_vol; ++k) {
+    // the accumulator tile of the first item: its rows were last written in the previous step, and nothing below
+    // depends on it until the chains start
+    f32x4 lo0, hi0, lo1, hi1;
+    if (cnt_cur > 0) acc_read(racc_c[0], lo0, hi0);
+    const int cnt_next = compact((k + 1) & 1);   // offset k+1 (no row has an offset past the last)
+    request_nb(k + 2);
+    load_w(Wn, k + 1);
+    PCC16_SYNC();
+    read_records((k + 1) & 1);
+    // items of offset k; behind each, the registers it leaves take the rows of the same item of offset k+1.  The
+    // gathers are unconditional (an item without a present row reads row 0, one cache line for the whole wave):
+    // loads under a branch would make the compiler's s_waitcnt vmcnt counts inexact, and an inexact count in front
+    // of an item's chains waits for the neighbour index and the weights requested at the top of this very step
+    if (cnt_cur > 0) {
+      if (cnt_cur > 16) acc_read(racc_c[1], lo1, hi1);
+      contract(0, lo0, hi0);
+      acc_write(racc_c[0], lo0, hi0);
+    }
+    gather(0);
+    if (cnt_cur > 16) {
+      if (cnt_cur > 32) acc_read(racc_c[2], lo0, hi0);
+      contract(1, lo1, hi1);
+      acc_write(racc_c[1], lo1, hi1);
+    }
+    gather(1);
+    if (cnt_cur > 32) {
+      if (cnt_cur > 48) acc_read(racc_c[3], lo1, hi1);
+      contract(2, lo0, hi0);
+      acc_write(racc_c[2], lo0, hi0);
+    }
+    gather(2);
+    if (cnt_cur > 48) {
+      contract(3, lo1, hi1);
+      acc_write(racc_c[3], lo1, hi1);
+    }
+    gather(3);
+#pragma unroll
+    for (int g = 0; g < NI; ++g) racc_c[g] = racc_n[g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Wc[j] = Wn[j];
+    cnt_cur = cnt_next;
+  }
+  PCC16_SYNC();
+
+  // ---- epilogue: the window's rows are contiguous in `out`: coalesced 16-B stores
+#pragma unroll
+  for (int it = 0; it < R / 8; ++it) {
+    const int r = it * 8 + grow;
+    float4 v = *reinterpret_cast<const float4*>(&acc_lds[r * AP + chunk * 4]);
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
+  }
+  if constexpr (HEAD) {
+    float hv = head_b[0];
+#pragma unroll
+    for (int ch = 0; ch < 32; ++ch) {
+      float v = acc_lds[lane * AP + ch];
+      if (relu) v = fmaxf(v, 0.f);
+      hv = fmaf(v, head_w[ch], hv);
+    }
+    if (row_ok) head_out[r_own] = hv;
+  }
+}

@@ -40,6 +40,58 @@
 // Layers of >= 200k rows run k_gconv_mfma_compact_w4 at the end of this file (weights shared through LDS).
 #pragma once
 
+// Experiment switch (build-time): priority of a wave while it runs the MFMA chain of a group.  Waves of one SIMD that
+// reach their chains together share the matrix pipe MFMA by MFMA and then also finish together — they fall into
+// step, and bookkeeping time and matrix time add up instead of overlapping.  A wave that holds a raised priority for
+// the length of its chain is served first: chains run one after the other and the waves drift apart.
+#ifndef PCC_CONV_PRIO
+#define PCC_CONV_PRIO 0
+#endif
+#if PCC_CONV_PRIO == 1
+#define PCC_PRIO_BEGIN() __builtin_amdgcn_s_setprio(3)
+#define PCC_PRIO_MID(s) do { } while (0)
+#define PCC_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#elif PCC_CONV_PRIO == 2
+#define PCC_PRIO_BEGIN() __builtin_amdgcn_s_setprio(1)
+#define PCC_PRIO_MID(s) do { if ((s) == 5) __builtin_amdgcn_s_setprio(2); if ((s) == 10) __builtin_amdgcn_s_setprio(3); } while (0)
+#define PCC_PRIO_END() __builtin_amdgcn_s_setprio(0)
+#elif PCC_CONV_PRIO == 3   /* the reverse: bookkeeping first, chains at the lowest priority */
+#define PCC_PRIO_BEGIN() __builtin_amdgcn_s_setprio(0)
+#define PCC_PRIO_MID(s) do { } while (0)
+#define PCC_PRIO_END() __builtin_amdgcn_s_setprio(3)
+#else
+#define PCC_PRIO_BEGIN() do { } while (0)
+#define PCC_PRIO_MID(s) do { } while (0)
+#define PCC_PRIO_END() do { } while (0)
+#endif
+#if PCC_CONV_PRIO == 3
+#define PCC_PRIO_KERNEL() __builtin_amdgcn_s_setprio(3)
+#elif PCC_CONV_PRIO == 4   /* static: workgroups that share a SIMD get different priorities */
+#define PCC_PRIO_KERNEL() do { switch ((blockIdx.x >> 3) & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); } } while (0)
+#else
+#define PCC_PRIO_KERNEL() do { } while (0)
+#endif
+
+// Diagnostic build only (-DPCC_CONV_STAMP=1; results are unchanged, timing is not): cycle stamps (s_memtime) at the
+// phase boundaries of an offset step of k_gconv_mfma_compact_w4, summed per wave over its 27 steps and written to a
+// buffer of their own (pcc_debug_stamps).  MI355X_MICROARCH.md, "in-kernel stamps".
+#ifndef PCC_CONV_STAMP
+#define PCC_CONV_STAMP 0
+#endif
+#if PCC_CONV_STAMP
+#define PCC_NSTAMP 10
+__device__ unsigned long long pcc_stamp_buf[4096 * PCC_NSTAMP];
+#define PCC_STAMP(i)                                                                  \
+  do {                                                                                \
+    unsigned long long t_;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    st_sum[i] += t_ - st_last;                                                        \
+    st_last = t_;                                                                     \
+  } while (0)
+#else
+#define PCC_STAMP(i) do { } while (0)
+#endif
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // UP: the rows are the 8 generative children (row 8p + o) of the rows of a PARENT level and `nbr` / `pitch` are
@@ -67,6 +119,7 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
   __shared__ uint8_t slot_row[2][R];
 
   const int lane = threadIdx.x;
+  PCC_PRIO_KERNEL();
   // XCD-aware window order: workgroups are dealt round-robin to the 8 XCDs, so workgroup b works on
   // window (b % 8) * (grid / 8) + b / 8: every XCD walks one contiguous eighth of the (Morton-sorted)
   // rows, and the neighbour rows that adjacent windows share are fetched into ONE L2 instead of eight
@@ -190,8 +243,12 @@ __global__ __launch_bounds__(64) void k_gconv_mfma_compact(
           xv[2 * it] = __uint_as_float(p0[0]);     xv[8 + 2 * it] = __uint_as_float(p0[1]);        \
           xv[2 * it + 1] = __uint_as_float(p1[0]); xv[8 + 2 * it + 1] = __uint_as_float(p1[1]);    \
         }                                                                                          \
-        _Pragma("unroll") for (int s = 0; s < 16; ++s)                                             \
+        PCC_PRIO_BEGIN();                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                           \
+          PCC_PRIO_MID(s);                                                                         \
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s], xv[s], acc, 0, 0, 0);                  \
+        }                                                                                          \
+        PCC_PRIO_END();                                                                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
           *reinterpret_cast<float4*>(ap + j * 8) =                                                 \
               make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);         \
@@ -273,6 +330,7 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_compact_w4(
   __shared__ __attribute__((aligned(16))) float wbuf[2][32 * 32];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  PCC_PRIO_KERNEL();
   float* const acc_lds = acc_all[wave];
   int32_t(*const slot_in)[R] = slot_in_all[wave];
   uint8_t(*const slot_row)[R] = slot_row_all[wave];
@@ -359,14 +417,18 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_compact_w4(
   } while (0)
 #define PCC_STEP(GC, GN, cur, k)                                                                   \
   do {                                                                                             \
+    PCC_STAMP(0);                                                                                  \
     const int cnt_next = compact((cur) ^ 1);                                                       \
+    PCC_STAMP(1);                                                                                  \
     load_nb((k) + 2);                                                                              \
+    PCC_STAMP(2);                                                                                  \
     *reinterpret_cast<float4*>(&wbuf[((k) + 1) & 1][threadIdx.x * 4]) = wq;                        \
     load_wq((k) + 2);                                                                              \
     PCC_WAVE_SYNC();                                                                               \
     PCC_GATHER(GN, (cur) ^ 1);                                                                     \
     float bc[16]; /* read behind the gathers' issue: its LDS latency overlaps the accumulator reads */ \
     _Pragma("unroll") for (int s = 0; s < 16; ++s) bc[s] = wbuf[(k) & 1][(2 * s + h) * 32 + i];    \
+    PCC_STAMP(3);                                                                                  \
     _Pragma("unroll") for (int grp = 0; grp < NG; ++grp) {                                         \
       if (grp * 32 < cnt_cur) {                                                                    \
         const int arow = (int)slot_row[cur][grp * 32 + i];                                         \
@@ -376,6 +438,7 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_compact_w4(
           const float4 c4 = *reinterpret_cast<const float4*>(ap + j * 8);                          \
           acc[4 * j + 0] = c4.x; acc[4 * j + 1] = c4.y; acc[4 * j + 2] = c4.z; acc[4 * j + 3] = c4.w; \
         }                                                                                          \
+        PCC_STAMP(4);                                                                              \
         float xv[16];                                                                              \
         _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                         \
           const u32x2 p0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(GC[grp][it].x),        \
@@ -385,18 +448,31 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_compact_w4(
           xv[2 * it] = __uint_as_float(p0[0]);     xv[8 + 2 * it] = __uint_as_float(p0[1]);        \
           xv[2 * it + 1] = __uint_as_float(p1[0]); xv[8 + 2 * it + 1] = __uint_as_float(p1[1]);    \
         }                                                                                          \
-        _Pragma("unroll") for (int s = 0; s < 16; ++s)                                             \
+        PCC_STAMP(5); /* gathered rows arrived (vmcnt), operands shaped */                        \
+        PCC_PRIO_BEGIN();                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 16; ++s) {                                           \
+          PCC_PRIO_MID(s);                                                                         \
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s], xv[s], acc, 0, 0, 0);                  \
+        }                                                                                          \
+        PCC_PRIO_END();                                                                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
           *reinterpret_cast<float4*>(ap + j * 8) =                                                 \
               make_float4(acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);         \
         PCC_WAVE_SYNC();                                                                           \
+        PCC_STAMP(6);                                                                              \
       }                                                                                            \
     }                                                                                              \
     cnt_cur = cnt_next;                                                                            \
+    PCC_STAMP(7);                                                                                  \
     PCC_WG_SYNC();                                                                                 \
+    PCC_STAMP(8);                                                                                  \
   } while (0)
 
+#if PCC_CONV_STAMP
+  unsigned long long st_sum[PCC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
   load_nb(0);
   int cnt_cur = compact(0);
   load_nb(1);
@@ -412,6 +488,12 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_compact_w4(
   }
 #undef PCC_STEP
 #undef PCC_GATHER
+  PCC_STAMP(9);
+#if PCC_CONV_STAMP
+  if (lane == 0 && UP && blockIdx.x >= 4096 && blockIdx.x < 4096 + 1024) {
+    for (int q = 0; q < PCC_NSTAMP; ++q) pcc_stamp_buf[((blockIdx.x - 4096) * 4 + wave) * PCC_NSTAMP + q] = st_sum[q];
+  }
+#endif
 
 #pragma unroll
   for (int it = 0; it < R / 8; ++it) {

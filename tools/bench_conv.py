@@ -61,8 +61,13 @@ def main():
             nbr = cs.nbr27()
             pairs = rt.count_nonneg(nbr)
             x = torch.randn((cs.n, 32), generator=gw, device="cuda").contiguous()
-            for label, fn in (("conv", lambda: rt.sparse_conv(x, nbr, w, b, True)),
-                              ("conv+head", lambda: rt.sparse_conv_head(x, nbr, w, b, True, hw, hb))):
+            fns = [("conv", lambda: rt.sparse_conv(x, nbr, w, b, True)),
+                   ("conv+head", lambda: rt.sparse_conv_head(x, nbr, w, b, True, hw, hb))]
+            if name == "cand_pruned":
+                # the form the native decoder runs: the candidates' rule book formed in-kernel from the parents' book
+                pn = pruned2.nbr27()
+                fns.append(("head_up", lambda: rt.sparse_conv_head_up(x, pn, w, b, True, hw, hb)))
+            for label, fn in fns:
                 for _ in range(3):
                     fn()
                 rt.sync()
