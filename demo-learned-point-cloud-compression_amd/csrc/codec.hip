@@ -409,10 +409,18 @@ int down2(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat*
   return PCC_OK;
 }
 
-int up2(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat* y) {
+// perm: the output rows are written in the channel order of pcc_conv16_perm (weight columns and bias permuted at
+// pcc_codec_create) — for the up stages of g_s, whose output only pcc_sparse_conv_head_up_perm reads
+int up2(pcc_codec* cd, const std::string& name, const Feat& x, int relu, Feat* y, bool perm = false) {
   const float *w, *b;
   const Tensor* tw;
   PCC_TRY(wb(cd, name, &w, &b, &tw));
+  if (perm) {
+    auto iw = cd->dev.find(name + ".weight#perm"), ib = cd->dev.find(name + ".bias#perm");
+    PCC_REQUIRE(iw != cd->dev.end() && ib != cd->dev.end(), PCC_E_ARG, "codec: no permuted weights for '%s'", name.c_str());
+    w = iw->second;
+    b = ib->second;
+  }
   const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
   CS* c;
   PCC_TRY(up_of(cd, x.cs, &c));
@@ -702,6 +710,46 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
       return nullptr;
     }
     cd->dev[k] = d;
+  }
+  // weights of the 32 -> 32 / 32 -> 64 convolutions in matrix-core operand order, once (pcc_conv_prepare); the three
+  // generative up stages of g_s additionally with their output columns in the order the following conv reads fastest
+  for (auto& kv : cd->t) {
+    const std::string& k = kv.first;
+    const Tensor& t = kv.second;
+    if (k.size() <= 7 || k.compare(k.size() - 7, 7, ".weight") != 0 || t.dtype != 0 || t.dims.size() != 3) continue;
+    const std::string layer = k.substr(0, k.size() - 7);
+    const bool is_up = layer.find(".up") != std::string::npos;
+    if (!is_up && (t.dims[0] == 27 || t.dims[0] == 8) && t.dims[1] == 32 && (t.dims[2] == 32 || t.dims[2] == 64) &&
+        cd->dev.count(k)) {
+      if (pcc_conv_prepare(ctx, cd->dev[k], (int)t.dims[0], 32, (int)t.dims[2]) != PCC_OK) {
+        for (auto& d : cd->dev) (void)hipFree(d.second);
+        pcc_destroy(cd->ctx);
+        delete cd;
+        return nullptr;
+      }
+    }
+    if (is_up && layer.compare(0, 4, "g_s.") == 0 && t.dims[0] == 8 && t.dims[1] == 32 && t.dims[2] == 32 &&
+        cd->t.count(layer + ".bias")) {
+      std::vector<float> wp((size_t)t.numel()), bp(32);
+      const float* bsrc = cd->t[layer + ".bias"].f32();
+      for (int64_t r = 0; r < 8 * 32; ++r)
+        for (int j = 0; j < 32; ++j) wp[(size_t)r * 32 + j] = t.f32()[r * 32 + pcc_conv16_perm(j)];
+      for (int j = 0; j < 32; ++j) bp[j] = bsrc[pcc_conv16_perm(j)];
+      float *dw = nullptr, *db = nullptr;
+      if (hipMalloc((void**)&dw, wp.size() * 4) != hipSuccess || hipMalloc((void**)&db, 128) != hipSuccess ||
+          hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(db, bp.data(), 128, hipMemcpyHostToDevice) != hipSuccess) {
+        pcc_set_error("pcc_codec_create: upload of the permuted '%s' failed", layer.c_str());
+        if (dw) (void)hipFree(dw);
+        if (db) (void)hipFree(db);
+        for (auto& d : cd->dev) (void)hipFree(d.second);
+        pcc_destroy(cd->ctx);
+        delete cd;
+        return nullptr;
+      }
+      cd->dev[layer + ".weight#perm"] = dw;
+      cd->dev[layer + ".bias#perm"] = db;
+    }
   }
   static const char* need[] = {"g_a.conv0.weight", "g_a.conv3.weight", "h_a.conv0.weight", "h_s.conv0.weight",
                                "g_s.color.weight", "entropy_bottleneck.quantized_cdf",
@@ -1461,22 +1509,27 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     PCC_TRY(offsets_of(cd, h.cs, &o0));
   }
   for (int j = 0; j < 3; ++j) {
-    Feat u;
-    PCC_TRY(up2(cd, "g_s.up" + std::to_string(j), h, 1, &u));
+    const std::string uname = "g_s.up" + std::to_string(j);
     const std::string cname = "g_s.conv" + std::to_string(j), oname = "g_s.occ" + std::to_string(j);
     const float *w, *b, *hw, *hb;
     const Tensor *tw, *thw;
     PCC_TRY(wb(cd, cname, &w, &b, &tw));
     PCC_TRY(wb(cd, oname, &hw, &hb, &thw));
     const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
+    // the conv that forms its rule book in-kernel reads candidate rows stored channel-permuted: the up stage writes them so
+    const bool fused = pcc_conv_up_fused() && cin == 32 && cout == 32 && cd->dev.count(uname + ".weight#perm");
+    Feat u;
+    PCC_TRY(up2(cd, uname, h, 1, &u, fused));
     const int64_t nu = u.cs->n;
     CODEC_ALLOC(feats, float, std::max<int64_t>(nu, 1) * cout);
     CODEC_ALLOC(logits, float, std::max<int64_t>(nu, 1));
-    if (pcc_conv_up_fused() && cin == 32 && cout == 32 && nu > 0) {
+    if (fused && nu > 0) {
       // rule book of the 8N candidates formed inside the conv from the book of the N rows below
       int32_t* pn;
       PCC_TRY(nbr27_of(cd, h.cs, &pn));
-      PCC_TRY(pcc_sparse_conv_head_up(ctx, u.f, h.cs->n, pn, h.cs->n, w, b, 1, feats, hw, hb, logits));
+      PCC_TRY(pcc_sparse_conv_head_up_perm(ctx, u.f, h.cs->n, pn, h.cs->n, w, b, 1, feats, hw, hb, logits));
+    } else if (nu == 0) {
+      // nothing to convolve
     } else {
       int32_t* nbr;
       PCC_TRY(nbr27_of(cd, u.cs, &nbr));

@@ -55,6 +55,8 @@ struct pcc_ctx {
   int64_t prof_only_d0;  // and, when >= 0, whose first dimension (rows) is this
   int prof_n, prof_cap;
   struct pcc_prof_rec* prof;
+  // weights in MFMA operand order, by device pointer (pcc_conv_prepare, conv.hip)
+  struct PccWeightCache* wcache;
 };
 
 struct pcc_prof_rec {
@@ -73,9 +75,18 @@ struct PccProfScope {
 
 #include "rans_gate.h"
 
-// True when pcc_sparse_conv_head_up has a kernel to run (the row-compacting MFMA family is selected and
-// PCC_CONV_UP=0 is not set); the whole-GOP decoder otherwise materialises the child rule books.
+// True when pcc_sparse_conv_head_up has a kernel to run (always, except under PCC_FORCE_SCALAR=1); the whole-GOP
+// decoder otherwise materialises the child rule books.
 bool pcc_conv_up_fused();
+// conv.hip: frees the operand-ordered weight copies of a context (pcc_destroy)
+void pcc_wcache_free(pcc_ctx* ctx);
+// conv.hip: pcc_sparse_conv_head_up on input rows whose 32 channels are stored in the order kConv16Perm below
+int pcc_sparse_conv_head_up_perm(pcc_ctx* ctx, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent,
+                                 int64_t parent_pitch, const float* d_w, const float* d_bias, int relu, float* d_out,
+                                 const float* d_head_w, const float* d_head_b, float* d_head_out);
+// storage position j of a permuted row holds channel pcc_conv16_perm(j) = 4 (j & 7) + (j >> 3): the eight MFMA B
+// operands of lane (slot, q) of k_gconv16 are then the 32 contiguous bytes at 8 q
+static inline int pcc_conv16_perm(int j) { return 4 * (j & 7) + (j >> 3); }
 
 // Reset the arena at the start of an API call.
 static inline void pcc_arena_reset(pcc_ctx* c) { c->arena_off = 0; }

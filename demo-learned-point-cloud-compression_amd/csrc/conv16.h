@@ -1,6 +1,6 @@
 // conv16.h — row-compacting 32 -> 32 gather-convolution on 16-slot items (included by conv.hip).
 //
-// Same arithmetic as conv_compact.h (out = bias; for k ascending over PRESENT neighbours, ci ascending:
+// Arithmetic contract of conv.hip (out = bias; for k ascending over PRESENT neighbours, ci ascending:
 // out = fmaf(x, w, out); v_mfma_f32_16x16x4_f32 is that chain four ci at a time), different shape of the work:
 //
 //   * the rows of a 64-row window that have offset k are packed into ITEMS of 16 slots (not groups of 32): a partly
@@ -11,8 +11,8 @@
 //   * one wave per workgroup and no workgroup barrier: a wave reads the weights of an offset as its MFMA operands
 //     straight from a pre-swizzled copy (pcc_conv16_swizzle: [k][lane][16] floats — four coalesced dwordx4 per
 //     lane and offset instead of sixteen dword loads), so waves never wait for each other;
-//   * nothing is waited for right after it is issued.  In the stamped build of k_gconv_mfma_compact_w4
-//     (tools/stamp_conv.py) a wave spent 17 % of its time waiting for the neighbour index it had just asked for,
+//   * nothing is waited for right after it is issued.  In the stamped build of the 32-slot, four-windows-per-workgroup
+//     kernel this one replaces (round 1; tools/stamp_conv.py) a wave spent 17 % of its time waiting for the neighbour index it had just asked for,
 //     16 % in the per-offset barrier, 10 % in the two dependent LDS round trips slot -> row -> accumulator and 12 %
 //     around the slot-list read in front of the gathers, against 31 % in its matrix chains.  Here the neighbour index
 //     of offset k+2 is only CONSUMED one step later (the child-index arithmetic of the UP form is deferred to the
@@ -23,15 +23,47 @@
 //
 // Lane (n, q) = (lane & 15, lane >> 4).  MFMA operands (D = A x B, A = W^T block 16 co x 4 ci, B = x^T block 4 ci x
 // 16 slots): A lane (m, q) holds W[4s + q][m (+16)], B lane (n, q) holds x[slot n][4s + q], D lane (n, q) holds
-// channels 4q .. 4q+3 (+16) of slot n — a row's accumulator is two 16-B pieces at row * AP + 4q and + 16.
+// channels 4q .. 4q+3 (+16) of slot n — a row's accumulator is two 16-B pieces, one per 16-channel plane.
 //
 // PERM: the input rows are stored channel-permuted, position 8q + s holding channel 4s + q: lane (n, q) reads its
 // eight B operands with two dwordx4 and no shaping.  The native decoder stores the output of the generative up
 // stages that way (permuted weight columns, codec.hip).  Natural layout (PERM = false): lane (n, q) reads channels
 // 8q .. 8q+7 and the four q-lanes of a slot transpose two 4 x 4 blocks with v_permlane32_swap / v_permlane16_swap.
+//
+// COUT = 64: a 32 -> 64 layer runs as grid.y = 2, workgroup (x, y) producing columns [32 y, 32 y + 32) of window x
+// (the h_s output layer, evaluated at the latent's rows only).
+//
+// Measured on bench.py's dominant launch (3,262,640 candidate rows, tools/bench_conv.py, same box): the 32-slot kernel
+// with four windows per workgroup 1.54 ms, this kernel 1.29 ms on natural rows and 1.23 ms on permuted rows (52 % of
+// the f32 matrix peak).  What was tried on top and changed nothing or made it slower (tools/ab_conv.sh): write-back of
+// an item delayed behind the next item's first MFMA pair, register renaming instead of copies between steps,
+// wave priorities (raised during a chain, lowered during a chain, static per workgroup: +11 .. +16 %), four waves
+// per SIMD (123 registers, no spill: +16 %), two or fewer waves per SIMD (+9 .. +22 %), weights or gathered rows
+// served from L1-resident addresses (+5 .. +12 %: the launch is not waiting for memory).
 #pragma once
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Diagnostic build only (-DPCC_CONV_STAMP=1; results are unchanged, timing is not): cycle stamps (s_memtime) at the
+// phase boundaries of an offset step, summed per wave over its steps and written to a buffer of their own
+// (pcc_debug_stamps, tools/stamp_conv.py).  MI355X_MICROARCH.md, "in-kernel stamps".
+#ifndef PCC_CONV_STAMP
+#define PCC_CONV_STAMP 0
+#endif
+#if PCC_CONV_STAMP
+#define PCC_NSTAMP 10
+__device__ unsigned long long pcc_stamp_buf[4096 * PCC_NSTAMP];
+#define PCC_STAMP(i)                                                                  \
+  do {                                                                                \
+    unsigned long long t_;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    st_sum[i] += t_ - st_last;                                                        \
+    st_last = t_;                                                                     \
+  } while (0)
+#else
+#define PCC_STAMP(i) do { } while (0)
+#endif
 
 #define PCC16_SYNC()                                         \
   do {                                                       \
@@ -40,42 +72,56 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 
-// weights [k_vol][32][32] (ci major) -> [k_vol][64 lanes][16]: lane (m, q): s = 0..7: W[4s+q][m], then W[4s+q][16+m]
-__global__ __launch_bounds__(256) void k_conv16_swizzle(const float* __restrict__ w, int k_vol, float* __restrict__ wsw) {
+// weights [k_vol][32][cout] (ci major) -> [k_vol][cout / 32][64 lanes][16]: lane (m, q) of column half y:
+// s = 0..7: W[4s+q][32y + m], then W[4s+q][32y + 16 + m]
+__global__ __launch_bounds__(256) void k_conv16_swizzle(const float* __restrict__ w, int k_vol, int cout,
+                                                        float* __restrict__ wsw) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= k_vol * 1024) return;
-  const int k = t >> 10, l = (t >> 4) & 63, e = t & 15;
+  const int ny = cout >> 5;
+  if (t >= k_vol * ny * 1024) return;
+  const int k = t / (ny * 1024), y = (t >> 10) % ny, l = (t >> 4) & 63, e = t & 15;
   const int m = l & 15, q = l >> 4, s = e & 7, hi = e >> 3;
-  wsw[t] = w[(k * 32 + 4 * s + q) * 32 + 16 * hi + m];
+  wsw[t] = w[(k * 32 + 4 * s + q) * cout + 32 * y + 16 * hi + m];
 }
 
-template <bool HEAD, bool UP, bool PERM>
+template <bool HEAD, bool UP, bool PERM, int COUT = 32>
 __global__ __launch_bounds__(64) void k_gconv16(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
     float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
     float* __restrict__ head_out) {
   constexpr int R = 64;    // rows of the window
-  constexpr int AP = 36;   // accumulator row pitch (floats)
+  // Accumulators in LDS: two planes (channels 0..15, 16..31) of 16-float rows; the 16-B piece q of a row sits at
+  // position (q + 2 (row >> 2)) & 3 of its plane row.  The hardware serves a ds_read_b128 / ds_write_b128 in groups of 16
+  // lanes that hold 16 different slots and two values of q; with a plain row-major layout (any pitch) consecutive rows
+  // then collide pairwise (SQ_LDS_BANK_CONFLICT was 40 % of SQ_LDS_IDX_ACTIVE), with this placement an item of 16
+  // consecutive rows is conflict-free and compacted row lists collide only by chance.
+  constexpr int HP = (R + 1) * 16;   // floats per plane (row R = sink of the pad slots)
   constexpr int NI = 4;    // items an offset can have
-  __shared__ __attribute__((aligned(16))) float acc_lds[(R + 1) * AP];   // row R = sink of the pad slots
+  __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
   __shared__ __attribute__((aligned(8))) int2 rec[2][R];                 // slot -> (input row, accumulator row)
 
+  static_assert(COUT == 32 || (COUT == 64 && !HEAD), "the fused head reads all channels of a row");
   const int lane = threadIdx.x;
-  // XCD-aware window order (conv_compact.h): every XCD walks one contiguous eighth of the Morton-sorted rows
+  const int ny = COUT / 32, ycol = COUT == 32 ? 0 : (int)blockIdx.y, col0 = 32 * ycol;
+  // XCD-aware window order: workgroups are dealt round-robin to the 8 XCDs, so workgroup b takes window (b % 8) *
+  // (grid / 8) + b / 8: every XCD walks one contiguous eighth of the Morton-sorted rows, and the neighbour rows that
+  // adjacent windows share are fetched into ONE L2 instead of eight
   const int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int64_t row0 = window * R;
   if (row0 >= n_out) return;
   const int n = lane & 15, q = lane >> 4;
   const int grow = lane >> 3, chunk = lane & 7;
 
-  {  // accumulators start at the bias
-    const float* bp = bias + chunk * 4;
+  // float index of channel block (plane `half`, piece qq) of `row`
+  auto acc_at = [&](int half, int row, int qq) -> int { return half * HP + row * 16 + (((qq + 2 * (row >> 2)) & 3) << 2); };
+  {  // accumulators start at the bias: lane (grow, chunk) fills piece `chunk` (channels 4 chunk ..) of rows grow + 8 it
+    const float* bp = bias + col0 + chunk * 4;
     const float4 b4 = make_float4(bp[0], bp[1], bp[2], bp[3]);
 #pragma unroll
     for (int it = 0; it < R / 8; ++it)
-      *reinterpret_cast<float4*>(&acc_lds[(it * 8 + grow) * AP + chunk * 4]) = b4;
-    if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[R * AP + lane * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&acc_lds[acc_at(chunk >> 2, it * 8 + grow, chunk & 3)]) = b4;
+    if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[acc_at(lane >> 2, R, lane & 3)]) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   // ---- neighbour index of this lane's row: requested two offsets ahead, turned into a row one offset later
@@ -98,34 +144,34 @@ __global__ __launch_bounds__(64) void k_gconv16(
       nb_raw = nbr[(int64_t)kk * pitch + rc];
     }
   };
-  // pack the rows that have the requested offset into slot records `b`; returns their count
+  // pack the rows that have the requested offset into slot records `b`; returns their count.  Every lane writes
+  // exactly one record (no divergent branch): a present row the record of its rank, an absent one a pad record (row 0 of
+  // `in`, accumulated into the sink row) in slot count + number of absent lanes in front of it
   auto compact = [&](int b) -> int {
     const bool p = nb_live && nb_raw >= 0;
     const int32_t src = UP ? ((nb_raw << 3) | nb_op) : nb_raw;
     const unsigned long long bal = __ballot(p);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
     const int cnt = __popcll(bal);
-    if (p) rec[b][rank] = make_int2(src, lane * (AP * 4));
-    const int sl = cnt + lane;   // every remaining slot is a pad: row 0 of `in`, accumulated into the sink row
-    if (sl < R) rec[b][sl] = make_int2(0, R * (AP * 4));
+    rec[b][p ? rank : cnt + lane - rank] = p ? make_int2(src, lane) : make_int2(0, R);
     return cnt;
   };
 
   float4 G[NI][2];              // gathered rows (B operands) of the items of one offset
-  float4 Wc[4], Wn[4];          // A operands of the current / next offset
-  int rin[NI], racc_c[NI], racc_n[NI];
+  float4 W0[4], W1[4];          // A operands of the even / odd offsets
+  int rin[NI], ra0[NI], ra1[NI];  // input rows of the next offset's slots; accumulator rows (byte offsets) even / odd
   auto load_w = [&](float4 (&W)[4], int k) {
     const int kk = k < k_vol ? k : k_vol - 1;
-    const float4* p = reinterpret_cast<const float4*>(wsw + ((int64_t)kk * 64 + lane) * 16);
+    const float4* p = reinterpret_cast<const float4*>(wsw + (((int64_t)kk * ny + ycol) * 64 + lane) * 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) W[j] = p[j];
   };
-  auto read_records = [&](int b) {
+  auto read_records = [&](int b, int (&racc)[NI]) {
 #pragma unroll
     for (int g = 0; g < NI; ++g) {
       const int2 r = rec[b][g * 16 + n];
       rin[g] = r.x;
-      racc_n[g] = r.y;
+      racc[g] = r.y;
     }
   };
   auto gather = [&](int g) {
@@ -133,20 +179,20 @@ __global__ __launch_bounds__(64) void k_gconv16(
     G[g][0] = *reinterpret_cast<const float4*>(xr);
     G[g][1] = *reinterpret_cast<const float4*>(xr + 4);
   };
-  auto acc_read = [&](int byte_off, f32x4& lo, f32x4& hi) {
-    const char* base = reinterpret_cast<const char*>(acc_lds) + byte_off + q * 16;
+  auto acc_read = [&](int row, f32x4& lo, f32x4& hi) {
+    const float* base = &acc_lds[acc_at(0, row, q)];
     const float4 a = *reinterpret_cast<const float4*>(base);
-    const float4 b = *reinterpret_cast<const float4*>(base + 64);
+    const float4 b = *reinterpret_cast<const float4*>(base + HP);
     lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w;
     hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; hi[3] = b.w;
   };
-  auto acc_write = [&](int byte_off, const f32x4& lo, const f32x4& hi) {
-    char* base = reinterpret_cast<char*>(acc_lds) + byte_off + q * 16;
+  auto acc_write = [&](int row, const f32x4& lo, const f32x4& hi) {
+    float* base = &acc_lds[acc_at(0, row, q)];
     *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
-    *reinterpret_cast<float4*>(base + 64) = make_float4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<float4*>(base + HP) = make_float4(hi[0], hi[1], hi[2], hi[3]);
   };
-  auto contract = [&](int g, f32x4& lo, f32x4& hi) {
-    float xv[8];
+  // B operands of item g in MFMA order
+  auto shape = [&](int g, float (&xv)[8]) {
     if constexpr (PERM) {
       xv[0] = G[g][0].x; xv[1] = G[g][0].y; xv[2] = G[g][0].z; xv[3] = G[g][0].w;
       xv[4] = G[g][1].x; xv[5] = G[g][1].y; xv[6] = G[g][1].z; xv[7] = G[g][1].w;
@@ -169,90 +215,105 @@ __global__ __launch_bounds__(64) void k_gconv16(
         for (int t = 0; t < 4; ++t) xv[2 * t + b] = __uint_as_float(m[b][t]);
       }
     }
+  };
+
+#if PCC_CONV_STAMP
+  unsigned long long st_sum[PCC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last;
+#endif
+  int cnt_cur;
+  // One offset step.  Wc / rc: operands and accumulator rows of offset k; Wn / rn take those of offset k+1.
+  // Item g: [tile of item g+1 requested] chains of item g, with the write-back of item g-1 behind their first pair
+  // (its results have long arrived by then; straight behind its own chains it would wait out their latency);
+  // the last item of the step writes itself back.  Items of one offset touch disjoint rows, so the order of these
+  // LDS accesses inside a step is free; across steps program order keeps every write in front of the next read.
+  auto step = [&](int k, float4 (&Wc)[4], float4 (&Wn)[4], int (&rc_)[NI], int (&rn)[NI]) {
+    PCC_STAMP(0);
+    f32x4 lo0, hi0, lo1, hi1;
+    if (cnt_cur > 0) acc_read(rc_[0], lo0, hi0);
+    const int cnt_next = compact((k + 1) & 1);   // offset k+1 (no row has an offset past the last)
+    PCC_STAMP(1);
+    request_nb(k + 2);
+    load_w(Wn, k + 1);
+    PCC16_SYNC();
+    read_records((k + 1) & 1, rn);
+    PCC_STAMP(2);
     const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
     const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
-      hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
-    }
+#define PCC16_ITEM(g, LO, HI, PLO, PHI)                                                              \
+    if (cnt_cur > 16 * (g)) {                                                                          \
+      const bool more = (g) + 1 < NI && cnt_cur > 16 * ((g) + 1);                                      \
+      float xv[8];                                                                                     \
+      shape(g, xv);                                                                                    \
+      LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
+      HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv[0], HI, 0, 0, 0);                            \
+      if ((g) > 0) acc_write(rc_[(g) > 0 ? (g) - 1 : 0], PLO, PHI);   /* item g-1: results long there */ \
+      if (more) acc_read(rc_[(g) + 1 < NI ? (g) + 1 : 0], PLO, PHI);                                   \
+      _Pragma("unroll") for (int s = 1; s < 8; ++s) {                                                  \
+        LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], LO, 0, 0, 0);                          \
+        HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], HI, 0, 0, 0);                          \
+      }                                                                                                \
+      if (!more) acc_write(rc_[g], LO, HI);                         /* last item of the step */        \
+    }                                                                                                  \
+    gather(g)
+    // The gathers are unconditional (an item without a present row reads row 0, one cache line for the whole wave):
+    // loads under a branch would make the compiler's s_waitcnt vmcnt counts inexact, and an inexact count in front
+    // of an item's chains waits for the neighbour index and the weights requested at the top of this very step
+    PCC16_ITEM(0, lo0, hi0, lo1, hi1);
+    PCC_STAMP(3);
+    PCC16_ITEM(1, lo1, hi1, lo0, hi0);
+    PCC16_ITEM(2, lo0, hi0, lo1, hi1);
+    PCC16_ITEM(3, lo1, hi1, lo0, hi0);
+#undef PCC16_ITEM
+    PCC_STAMP(4);
+    cnt_cur = cnt_next;
   };
 
   // ---- prologue: offset 0 compacted and gathered, offset 1 requested
   request_nb(0);
-  int cnt_cur = compact(0);
+  cnt_cur = compact(0);
   request_nb(1);
-  load_w(Wc, 0);
+  load_w(W0, 0);
   PCC16_SYNC();
-  read_records(0);
+  read_records(0, ra0);
 #pragma unroll
-  for (int g = 0; g < NI; ++g) {
-    racc_c[g] = racc_n[g];
-    gather(g);
-  }
-
-  for (int k = 0; k < k_vol; ++k) {
-    // the accumulator tile of the first item: its rows were last written in the previous step, and nothing below
-    // depends on it until the chains start
-    f32x4 lo0, hi0, lo1, hi1;
-    if (cnt_cur > 0) acc_read(racc_c[0], lo0, hi0);
-    const int cnt_next = compact((k + 1) & 1);   // offset k+1 (no row has an offset past the last)
-    request_nb(k + 2);
-    load_w(Wn, k + 1);
-    PCC16_SYNC();
-    read_records((k + 1) & 1);
-    // items of offset k; behind each, the registers it leaves take the rows of the same item of offset k+1.  The
-    // gathers are unconditional (an item without a present row reads row 0, one cache line for the whole wave):
-    // loads under a branch would make the compiler's s_waitcnt vmcnt counts inexact, and an inexact count in front
-    // of an item's chains waits for the neighbour index and the weights requested at the top of this very step
-    if (cnt_cur > 0) {
-      if (cnt_cur > 16) acc_read(racc_c[1], lo1, hi1);
-      contract(0, lo0, hi0);
-      acc_write(racc_c[0], lo0, hi0);
-    }
-    gather(0);
-    if (cnt_cur > 16) {
-      if (cnt_cur > 32) acc_read(racc_c[2], lo0, hi0);
-      contract(1, lo1, hi1);
-      acc_write(racc_c[1], lo1, hi1);
-    }
-    gather(1);
-    if (cnt_cur > 32) {
-      if (cnt_cur > 48) acc_read(racc_c[3], lo1, hi1);
-      contract(2, lo0, hi0);
-      acc_write(racc_c[2], lo0, hi0);
-    }
-    gather(2);
-    if (cnt_cur > 48) {
-      contract(3, lo1, hi1);
-      acc_write(racc_c[3], lo1, hi1);
-    }
-    gather(3);
-#pragma unroll
-    for (int g = 0; g < NI; ++g) racc_c[g] = racc_n[g];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Wc[j] = Wn[j];
-    cnt_cur = cnt_next;
+  for (int g = 0; g < NI; ++g) gather(g);
+#if PCC_CONV_STAMP
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+  for (int k = 0; k < k_vol; k += 2) {
+    step(k, W0, W1, ra0, ra1);
+    if (k + 1 < k_vol) step(k + 1, W1, W0, ra1, ra0);
   }
   PCC16_SYNC();
+#if PCC_CONV_STAMP
+  if (lane == 0 && blockIdx.x >= 16384 && blockIdx.x < 16384 + 4096) {
+    for (int j = 0; j < PCC_NSTAMP; ++j) pcc_stamp_buf[(blockIdx.x - 16384) * PCC_NSTAMP + j] = st_sum[j];
+  }
+#endif
 
   // ---- epilogue: the window's rows are contiguous in `out`: coalesced 16-B stores
 #pragma unroll
   for (int it = 0; it < R / 8; ++it) {
     const int r = it * 8 + grow;
-    float4 v = *reinterpret_cast<const float4*>(&acc_lds[r * AP + chunk * 4]);
+    float4 v = *reinterpret_cast<const float4*>(&acc_lds[acc_at(chunk >> 2, r, chunk & 3)]);
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
+    if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * COUT + col0 + chunk * 4) = v;
   }
   if constexpr (HEAD) {
     float hv = head_b[0];
 #pragma unroll
-    for (int ch = 0; ch < 32; ++ch) {
-      float v = acc_lds[lane * AP + ch];
-      if (relu) v = fmaxf(v, 0.f);
-      hv = fmaf(v, head_w[ch], hv);
+    for (int c4 = 0; c4 < 8; ++c4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, lane, c4 & 3)]);
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = vv[j];
+        if (relu) v = fmaxf(v, 0.f);
+        hv = fmaf(v, head_w[4 * c4 + j], hv);
+      }
     }
     if (row_ok) head_out[r_own] = hv;
   }

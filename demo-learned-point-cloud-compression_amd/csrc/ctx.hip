@@ -49,6 +49,7 @@ extern "C" void pcc_destroy(pcc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  pcc_wcache_free(c);
   if (c->arena) (void)hipFree(c->arena);
   if (c->pinned) (void)hipHostFree(c->pinned);
   (void)hipEventDestroy(c->ev0);

@@ -344,6 +344,13 @@ class Runtime:
                                                _ptr(head_b), _ptr(logits)), "pcc_sparse_conv_head_up")
         return out, logits
 
+    def conv_prepare(self, w):
+        """register the weights [k, 32, 32|64] of a layer: re-arranged once, found by pointer afterwards (pcc_conv_prepare)"""
+        check(self.lib.pcc_conv_prepare(self.ctx, _ptr(w), w.shape[0], w.shape[1], w.shape[2]), "pcc_conv_prepare")
+
+    def conv_forget(self, w):
+        check(self.lib.pcc_conv_forget(self.ctx, _ptr(w)), "pcc_conv_forget")
+
     def convT_gen(self, x, w, b, relu):
         n, cin, cout = x.shape[0], w.shape[1], w.shape[2]
         assert x.shape[1] == cin and w.shape[0] == 8

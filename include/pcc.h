@@ -209,6 +209,16 @@ int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                     const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
                     int64_t n_out, const float* d_w, const float* d_bias,
                     int cin, int cout, int relu, float* d_out);
+/* Layer weights, prepared once.  The (32,32) and (32,64) layers read their weights
+ * as matrix-core operands from a copy in operand order (csrc/conv16.h).  A weight
+ * tensor [k_vol][cin][cout] registered here — what load_model / model.to(device)
+ * do once per layer (codec_pipeline.py:56-72) — is re-arranged now and found again
+ * by its device pointer in every later pcc_sparse_conv* call on this ctx; for an
+ * unregistered pointer the copy is made in front of each launch (same results).
+ * Call again after the tensor's contents changed; pcc_conv_forget before its
+ * memory is freed or reused.  Shapes without such a form: PCC_E_ARG. */
+int pcc_conv_prepare(pcc_ctx* ctx, const float* d_w, int k_vol, int cin, int cout);
+int pcc_conv_forget(pcc_ctx* ctx, const float* d_w);
 /* the same layer with the 1x1 occupancy head of g_s fused into its epilogue:
  * d_head_out[n] = head_b[0] + sum_c fmaf(out[n][c], head_w[c]) (c ascending) —
  * bit-identical to pcc_linear(cout -> 1) applied to d_out, without re-reading it. */

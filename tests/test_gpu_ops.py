@@ -318,9 +318,9 @@ def test_sparse_conv_fused_head_bit_exact(rt, oracle, clouds, name, cin):
 
 
 def _structured_cloud(kind, n):
-    """coordinate sets that exercise the row-compacting 32->32 kernel (64-row windows, groups of 32):
-    dense: a full cube, every offset present for the inner rows (two full groups per offset);
-    dust: isolated voxels, only the centre offset present (single partly filled group, 26 empty offsets);
+    """coordinate sets that exercise the row-compacting 32->32 kernel (64-row windows, items of 16 slots):
+    dense: a full cube, every offset present for the inner rows (four full items per offset);
+    dust: isolated voxels, only the centre offset present (single partly filled item, 26 empty offsets);
     children: all 8 children of scattered stride-2 parents (the decoder's candidate sets);
     line: a 1-voxel-wide diagonal, 3 offsets present"""
     rng = np.random.default_rng(n)
@@ -341,9 +341,9 @@ def _structured_cloud(kind, n):
 
 
 @pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
-@pytest.mark.parametrize("n", [1, 31, 33, 63, 64, 65, 127, 129, 1000, 4099])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 31, 33, 47, 49, 63, 64, 65, 127, 129, 1000, 4099])
 def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
-    """window / group boundaries of k_gconv_mfma_compact (rows 63|64|65, groups 32|33) on neighbourhoods
+    """window / item boundaries of k_gconv16 (rows 63|64|65, items 16|17, 32|33, 48|49) on neighbourhoods
     from empty to full, plain and fused-head entry points, against the oracle's fmaf chain"""
     rng = np.random.default_rng(1000 + n)
     keys = sorted_keys(oracle, _structured_cloud(kind, n))
@@ -360,7 +360,7 @@ def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
     refr = np.maximum(ref, 0)
     assert np.array_equal(host(feats), refr)
     assert np.array_equal(host(logits), oracle.linear(refr, hw, hb)[:, 0])
-    # the 32 -> 64 layer (dense-tile kernel) on the same neighbourhoods
+    # the 32 -> 64 layer (the two column halves as grid.y) on the same neighbourhoods
     w64, b64 = _weights(rng, 27, 32, 64)
     out64 = rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w64), dev(rt, b64), True)
     assert np.array_equal(host(out64), oracle.sparse_conv(x, nbr, w64, b64, True))
@@ -406,9 +406,9 @@ def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
     assert np.array_equal(got, oracle.map27(ckeys[keep], 1))
 
 
-def test_conv_head_up_refuses_when_family_is_off(rt):
-    """the fused form exists only in the row-compacting MFMA family: any other selection must be refused,
-    not silently computed by something else"""
+def test_conv_head_up_refuses_under_the_scalar_switch(rt):
+    """the form with the in-kernel rule book exists only as an MFMA kernel: under PCC_FORCE_SCALAR=1 it must be
+    refused (the decoder then materialises the child rule books), not silently computed by something else"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -421,11 +421,35 @@ def test_conv_head_up_refuses_when_family_is_off(rt):
             "hw = torch.zeros((32, 1), device='cuda'); hb = torch.zeros(1, device='cuda')\n"
             "try:\n    rt.sparse_conv_head_up(x, nb, w, b, True, hw, hb)\n"
             "except rtm.PccError as e:\n    print('REFUSED', e.code)\nelse:\n    print('RAN')\n") % root
-    for env, want in (({"PCC_FORCE_SCALAR": "1"}, "REFUSED"), ({"PCC_CONV_UP": "0"}, "REFUSED"),
-                      ({"PCC_CONV_COMPACT": "0"}, "REFUSED"), ({}, "RAN")):
+    for env, want in (({"PCC_FORCE_SCALAR": "1"}, "REFUSED"), ({}, "RAN")):
         out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
                              timeout=300)
         assert want in out.stdout, (env, out.stdout, out.stderr[-400:])
+
+
+def test_prepared_weights_give_the_same_bits(rt, oracle):
+    """pcc_conv_prepare: a registered weight tensor is re-arranged once and found by its pointer; the results equal
+    those of the per-call path and the oracle, a refresh after the contents changed is honoured, and forgetting
+    the pointer falls back to the per-call copy"""
+    rng = np.random.default_rng(77)
+    keys = sorted_keys(oracle, _structured_cloud("children", 700))
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(len(keys), 32)).astype(np.float32)
+    for cout in (32, 64):
+        w, b = _weights(rng, 27, 32, cout)
+        xd, nd, wd, bd = dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b)
+        ref = oracle.sparse_conv(x, nbr, w, b, True)
+        assert np.array_equal(host(rt.sparse_conv(xd, nd, wd, bd, True)), ref)
+        rt.conv_prepare(wd)
+        assert np.array_equal(host(rt.sparse_conv(xd, nd, wd, bd, True)), ref)
+        w2 = (w * np.float32(0.5)).astype(np.float32)
+        wd.copy_(dev(rt, w2))                                  # same pointer, new contents
+        rt.conv_prepare(wd)
+        assert np.array_equal(host(rt.sparse_conv(xd, nd, wd, bd, True)), oracle.sparse_conv(x, nbr, w2, b, True))
+        rt.conv_forget(wd)
+        assert np.array_equal(host(rt.sparse_conv(xd, nd, wd, bd, True)), oracle.sparse_conv(x, nbr, w2, b, True))
+    with pytest.raises(pkg("runtime").PccError):
+        rt.conv_prepare(dev(rt, np.zeros((27, 4, 32), np.float32)))   # the 4 -> 32 layer has no pre-arranged form
 
 
 @pytest.mark.parametrize("cout", [32, 64])
@@ -449,23 +473,6 @@ def test_conv_on_a_subset_of_the_rows(rt, oracle, cout, n, m):
     got = host(rt.gather_rows_or_zero(out, me))
     ref = np.where(rows[:, None] >= 0, full[np.maximum(rows, 0)], 0).astype(np.float32)
     assert np.array_equal(got, ref)
-
-
-def test_conv_ops_on_the_shared_weight_kernel():
-    """layers of >= 200k rows run four windows per workgroup with the weights shared through LDS; the op tests above
-    are far smaller, so they are run once more in a child process with PCC_CONV_W4=1 (that kernel for every size:
-    windows / quarter-workgroups past the end, K = 8 and 27, fused head, in-kernel rule book, pitch)"""
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    sel = ("row_compaction or conv_head_up_forms or pitch_and_foreign or sparse_conv_down or sparse_conv3_bit_exact")
-    # second child: the one-window-per-workgroup kernel with 64-row windows at these sizes (the default gives
-    # launches of <= 64k rows 32-row windows, which is what the tests above exercise in this process)
-    for env in ({"PCC_CONV_W4": "1"}, {"PCC_CONV_HALFW": "0"}):
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-x", "-q", "-k", sel],
-                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, str(env) + r.stdout[-3000:] + r.stderr[-1000:]
-        assert " passed" in r.stdout
 
 
 def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):

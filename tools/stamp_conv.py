@@ -17,6 +17,9 @@ sys.path.insert(0, ROOT)
 PKG = "demo-learned-point-cloud-compression_amd"
 NAMES = ["top", "compact(k+1)", "load_nb(k+2)", "w/slots/gather issue", "acc read", "gather wait+shape",
          "mfma+write", "pre-barrier", "barrier", "tail"]
+if os.environ.get("PCC_CONV16"):
+    NAMES = ["loop back", "acc0 read + compact(k+1)", "requests + records", "item 0", "items 1-3 + gathers", "-", "-", "-",
+             "-", "-"]
 
 
 def main():
