@@ -47,6 +47,12 @@ PROTOTYPES = {
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
     "pcc_decode_fetch_packed": (i32, [vp, vp, vp]),
     "pcc_sparse_conv_head_up": (i32, [vp, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp, vp]),
+    "pcc_rans_dev_create": (vp, [vp, i32, vp, vp, i32]),
+    "pcc_rans_dev_destroy": (None, [vp]),
+    "pcc_rans_dev_bound": (i64, [i64]),
+    "pcc_rans_encode_dev": (i32, [vp, vp, vp, vp, i64, i64, i32, vp, i64, pi64]),
+    "pcc_rans_stream_info": (i32, [vp, i64, pi64, pi64, pi64]),
+    "pcc_rans_decode_dev": (i32, [vp, vp, vp, i64, i64, i64, i64, vp, i64, vp, vp]),
     "pcc_conv_prepare": (i32, [vp, vp, i32, i32, i32]),
     "pcc_conv_forget": (i32, [vp, vp]),
     "pcc_level_counts": (i32, [vp, vp, i64, i32, i32, pi64, C.POINTER(C.c_int)]),

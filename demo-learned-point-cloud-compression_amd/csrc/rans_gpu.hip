@@ -1,0 +1,467 @@
+// rans_gpu.hip — range-ANS coding of the latent symbols ON the GPU: the wave-interleaved stream of container
+// version 1 (a flagged extension; version 0 is the reference's single stream, coded on the host: rans_host.cpp).
+//
+// Replaces, for containers that carry the flag, compressai.ans.RansEncoder.encode_with_indexes / RansDecoder.
+// decode_with_indexes as called from entropy_bottleneck / gaussian_conditional .compress / .decompress
+// (sender/encoder/codec_pipeline.py:305-306,426-430; receiver/decoder/codec_parallel.py:307,398-400).  The
+// reference's stream is ONE rANS state over the channel-major [C, N] symbols: serial by construction, 2.0 ms to encode
+// and 2.3 ms to decode per quality of a 1M-point frame on a host core, with the GPU idle meanwhile and a PCIe round trip
+// of the symbols around it.  Here the arithmetic of a coding step is unchanged (64-bit state, L = 2^31, 32-bit
+// renormalisation words, 16-bit CDFs, the escape bin followed by 4-bit bypass nibbles — pcc_oracle.c:326 restates it)
+// but the symbols are dealt to 64 independent states per wave:
+//
+//   stream  = u32 'PCI1' | u32 n | u32 T | u32 n_chunks | u32 words[n_chunks] | chunk payloads
+//   chunk c = symbols [c 64 T, (c+1) 64 T): step t of lane l codes symbol c 64 T + 64 t + l (coalesced)
+//   payload = 64 x (state lo, state hi) | block(step 0, round 0) | block(0, 1) .. | block(1, 0) ..
+//   round 0 of a step is the symbol's bin, rounds 1.. are the bypass nibbles of the lanes whose symbol escaped;
+//   a block holds the renormalisation words the decoder needs after that round, in ascending lane order.
+//
+// The encoder walks steps and rounds backwards and grows its chunk downwards from the end of a private buffer
+// (ballot + mbcnt give a lane its place in a block), so the decoder reads every chunk strictly forwards.  One wave
+// per chunk, four chunks per workgroup; the CDF rows (27k entries for the 64 Gaussian tables) live in LDS as uint16
+// and a symbol is found by binary search there.  All integer: bit-exact against oracle/pcc_oracle.c
+// (orc_rans_interleaved_*), which restates the same order sequentially.
+#include "common.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t kMagic = 0x31494350u;  // "PCI1" little-endian
+constexpr uint64_t kL = 1ull << 31;
+constexpr int kLanes = 64;
+constexpr int kChunksPerWg = 4;
+constexpr int kHeaderWords = 4;
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+struct pcc_rans_dev {
+  uint16_t* d_cdf = nullptr;   // all rows back to back; an entry of 65536 (end of a row) is stored as 0
+  int32_t* d_row = nullptr;    // [3 n_cdf]: entry offset, length, symbol offset of every row
+  int n_cdf = 0;
+  int64_t entries = 0;
+  int device = 0;
+  size_t lds_bytes() const { return ((size_t)entries * 2 + 15) / 16 * 16 + (size_t)n_cdf * 12; }
+};
+
+extern "C" pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                                             const int32_t* h_offsets, int n_cdf) {
+  if (!h_cdfs || !h_sizes || !h_offsets || n_cdf < 1 || n_cdf > 256 || cdf_pitch < 2) {
+    pcc_set_error("pcc_rans_dev_create: bad argument");
+    return nullptr;
+  }
+  std::vector<uint16_t> flat;
+  std::vector<int32_t> row((size_t)3 * n_cdf);
+  for (int r = 0; r < n_cdf; ++r) {
+    const int len = h_sizes[r];
+    const int32_t* c = h_cdfs + (int64_t)r * cdf_pitch;
+    bool ok = len >= 2 && len <= cdf_pitch && c[0] == 0 && c[len - 1] == 65536;
+    for (int j = 0; ok && j + 1 < len; ++j) ok = c[j + 1] > c[j];
+    if (!ok) {
+      pcc_set_error("pcc_rans_dev_create: row %d is not a 16-bit CDF (length %d)", r, len);
+      return nullptr;
+    }
+    row[3 * r] = (int32_t)flat.size();
+    row[3 * r + 1] = len;
+    row[3 * r + 2] = h_offsets[r];
+    for (int j = 0; j < len; ++j) flat.push_back((uint16_t)(c[j] & 0xFFFF));
+  }
+  pcc_rans_dev* t = new (std::nothrow) pcc_rans_dev();
+  if (!t) return nullptr;
+  t->n_cdf = n_cdf;
+  t->entries = (int64_t)flat.size();
+  if (t->lds_bytes() > 64 * 1024) {   // dynamic LDS of a launch without further attributes
+    pcc_set_error("pcc_rans_dev_create: %lld CDF entries do not fit the LDS of a workgroup", (long long)t->entries);
+    delete t;
+    return nullptr;
+  }
+  (void)hipGetDevice(&t->device);
+  if (hipMalloc((void**)&t->d_cdf, flat.size() * 2) != hipSuccess || hipMalloc((void**)&t->d_row, row.size() * 4) != hipSuccess ||
+      hipMemcpy(t->d_cdf, flat.data(), flat.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(t->d_row, row.data(), row.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    pcc_set_error("pcc_rans_dev_create: upload failed");
+    if (t->d_cdf) (void)hipFree(t->d_cdf);
+    if (t->d_row) (void)hipFree(t->d_row);
+    delete t;
+    return nullptr;
+  }
+  return t;
+}
+
+extern "C" void pcc_rans_dev_destroy(pcc_rans_dev* t) {
+  if (!t) return;
+  (void)hipFree(t->d_cdf);
+  (void)hipFree(t->d_row);
+  delete t;
+}
+
+// steps per chunk for an array of n symbols: whole arrays of up to 32768 symbols are one chunk, larger ones are cut
+// into chunks of 64 x 512 (every chunk costs 512 B of final states: 5 % of a 2-bit-per-symbol stream at 512 steps)
+static inline int64_t steps_for(int64_t n) { return n > 32768 ? 512 : std::max<int64_t>((n + kLanes - 1) / kLanes, 1); }
+static inline int64_t chunks_for(int64_t n, int64_t T) { return std::max<int64_t>((n + kLanes * T - 1) / (kLanes * T), 1); }
+
+extern "C" int64_t pcc_rans_dev_bound(int64_t n) {
+  if (n < 0) return 0;
+  const int64_t T = steps_for(n), nc = chunks_for(n, T);
+  // header + per chunk: states + up to one word per coding round (a symbol that escapes has up to 10 rounds)
+  return 4 * (kHeaderWords + nc + nc * (2 * kLanes + kLanes * T * 11));
+}
+
+// ---- shared device pieces -------------------------------------------------------------------------------------
+struct RansView {
+  const uint16_t* cdf;
+  const int32_t* row;
+  int n_cdf;
+  int64_t entries;
+};
+
+// LDS image: uint16 cdf[entries] (padded to 16 B) | int32 row[3 n_cdf]
+__device__ __forceinline__ void stage_tables(const RansView& v, uint16_t* s_cdf, int32_t* s_row) {
+  for (int64_t i = threadIdx.x; i < v.entries; i += blockDim.x) s_cdf[i] = v.cdf[i];
+  for (int i = threadIdx.x; i < 3 * v.n_cdf; i += blockDim.x) s_row[i] = v.row[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ int lane_rank(unsigned long long bal) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+}
+
+// ---- encoder -----------------------------------------------------------------------------------------------------
+// One wave per chunk.  work: per stream and chunk a private buffer of cap_words; the chunk ends at the buffer's end.
+// words_out[s * n_chunks + c] = words of the chunk (0xFFFFFFFF: the buffer was too small).
+__global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __restrict__ sym,
+                                                  const uint8_t* __restrict__ idx, int64_t idx_run, int64_t n,
+                                                  int64_t T, int64_t n_chunks, uint32_t* __restrict__ work,
+                                                  int64_t cap_words, uint32_t* __restrict__ words_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  uint16_t* s_cdf = reinterpret_cast<uint16_t*>(s_raw);
+  int32_t* s_row = reinterpret_cast<int32_t*>(s_raw + ((size_t)tv.entries * 2 + 15) / 16 * 16);
+  stage_tables(tv, s_cdf, s_row);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * kChunksPerWg + wave;
+  const int64_t s = blockIdx.y;
+  if (c >= n_chunks) return;
+  const int32_t* ssym = sym + s * n;
+  const uint8_t* sidx = idx ? idx + s * n : nullptr;
+  uint32_t* buf = work + (s * n_chunks + c) * cap_words;
+  int64_t ptr = cap_words;   // words [ptr, cap_words) are written
+  bool overflow = false;
+  uint64_t x = kL;
+  const int64_t base = c * kLanes * T;
+
+  for (int64_t t = T - 1; t >= 0; --t) {
+    const int64_t i = base + t * kLanes + lane;
+    const bool act = i < n;
+    int32_t start = 0, freq = 1, nb = 0;
+    uint32_t raw = 0;
+    bool esc = false;
+    if (act) {
+      const int r = sidx ? (int)sidx[i] : (int)(i / idx_run);
+      const int off = s_row[3 * r], len = s_row[3 * r + 1];
+      const int32_t max_value = len - 2;
+      int32_t v = ssym[i] - s_row[3 * r + 2];
+      if (v < 0) {
+        raw = (uint32_t)(-2 * (int64_t)v - 1);
+        v = max_value;
+      } else if (v >= max_value) {
+        raw = (uint32_t)(2 * ((int64_t)v - max_value));
+        v = max_value;
+      }
+      esc = v == max_value;
+      if (esc)
+        while (nb < 8 && (raw >> (4 * nb)) != 0) ++nb;
+      const uint32_t c0 = s_cdf[off + v], c1 = s_cdf[off + v + 1];
+      start = (int32_t)c0;
+      freq = (int32_t)((c1 - c0) & 0xFFFFu);
+      if (freq == 0) freq = 65536;
+    }
+    // bypass rounds of the escaped lanes, last round first: round 1 = nibble count, round 2 + j = nibble j
+    if (__ballot(esc) != 0ull) {
+      for (int r = 9; r >= 1; --r) {
+        const bool in = esc && r <= 1 + nb;
+        if (__ballot(in) == 0ull) continue;
+        const bool need = in && x >= (1ull << 59);   // ((L >> 16) << 32) * 2^12
+        const unsigned long long bal = __ballot(need);
+        const int cnt = __popcll(bal);
+        if (cnt) {
+          if (ptr - cnt < 2 * kLanes) overflow = true;
+          else {
+            ptr -= cnt;
+            if (need) buf[ptr + lane_rank(bal)] = (uint32_t)x;
+          }
+        }
+        if (need) x >>= 32;
+        if (in) {
+          const uint32_t val = r == 1 ? (uint32_t)nb : (raw >> (4 * (r - 2))) & 15u;
+          x = (x << 4) | val;
+        }
+      }
+    }
+    {  // round 0: the symbol's bin
+      const bool need = act && x >= ((uint64_t)(uint32_t)freq << 47);   // ((L >> 16) << 32) * freq
+      const unsigned long long bal = __ballot(need);
+      const int cnt = __popcll(bal);
+      if (cnt) {
+        if (ptr - cnt < 2 * kLanes) overflow = true;
+        else {
+          ptr -= cnt;
+          if (need) buf[ptr + lane_rank(bal)] = (uint32_t)x;
+        }
+      }
+      if (need) x >>= 32;
+      if (act) x = ((x / (uint32_t)freq) << 16) + (x % (uint32_t)freq) + (uint32_t)start;
+    }
+  }
+  if (!overflow) {
+    ptr -= 2 * kLanes;
+    buf[ptr + 2 * lane] = (uint32_t)x;
+    buf[ptr + 2 * lane + 1] = (uint32_t)(x >> 32);
+  }
+  if (lane == 0) words_out[s * n_chunks + c] = overflow ? 0xFFFFFFFFu : (uint32_t)(cap_words - ptr);
+}
+
+// header + chunk table + payloads of every stream, packed: workgroup (c, s) moves chunk c of stream s (c == n_chunks:
+// writes the header); len_out[s] = bytes of stream s, or -1 when a chunk overflowed its buffer
+__global__ __launch_bounds__(256) void k_rans_pack(const uint32_t* __restrict__ work, int64_t cap_words,
+                                                   const uint32_t* __restrict__ words, int64_t n, int64_t T,
+                                                   int64_t n_chunks, uint8_t* __restrict__ out, int64_t cap_each,
+                                                   long long* __restrict__ len_out) {
+  __shared__ unsigned long long s_sum[256];
+  __shared__ int s_bad;
+  const int64_t c = blockIdx.x, s = blockIdx.y;
+  const uint32_t* w = words + s * n_chunks;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  // words in front of chunk c (all chunks for the header block), and whether any chunk overflowed
+  unsigned long long part = 0;
+  const int64_t upto = c < n_chunks ? c : n_chunks;
+  for (int64_t j = threadIdx.x; j < n_chunks; j += blockDim.x) {
+    const uint32_t v = w[j];
+    if (v == 0xFFFFFFFFu) s_bad = 1;
+    if (j < upto) part += v;
+  }
+  s_sum[threadIdx.x] = part;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) s_sum[threadIdx.x] += s_sum[threadIdx.x + d];
+    __syncthreads();
+  }
+  const unsigned long long before = s_sum[0];
+  const bool bad = s_bad != 0;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + s * cap_each);
+  const unsigned long long head = kHeaderWords + (unsigned long long)n_chunks;
+  if (c == n_chunks) {
+    const unsigned long long total = head + before;
+    const bool fits = !bad && (long long)(total * 4) <= cap_each;
+    if (threadIdx.x == 0) len_out[s] = fits ? (long long)(total * 4) : -1;
+    if (!fits) return;
+    if (threadIdx.x == 0) {
+      o[0] = kMagic;
+      o[1] = (uint32_t)n;
+      o[2] = (uint32_t)T;
+      o[3] = (uint32_t)n_chunks;
+    }
+    for (int64_t j = threadIdx.x; j < n_chunks; j += blockDim.x) o[kHeaderWords + j] = w[j];
+    return;
+  }
+  if (bad) return;
+  const uint32_t cw = w[c];
+  if ((long long)((head + before + cw) * 4) > cap_each) return;   // the header block reports it
+  const uint32_t* src = work + (s * n_chunks + c) * cap_words + (cap_words - cw);
+  uint32_t* dst = o + head + before;
+  for (uint32_t j = threadIdx.x; j < cw; j += blockDim.x) dst[j] = src[j];
+}
+
+// ---- decoder -----------------------------------------------------------------------------------------------------
+// status (int32): OR of 1 = a chunk ran out of words, 2 = malformed escape
+__global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* __restrict__ in /* the stream */,
+                                                  const uint8_t* __restrict__ idx, int64_t idx_run, int64_t n,
+                                                  int64_t T, int64_t n_chunks, int32_t* __restrict__ sym,
+                                                  int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  uint16_t* s_cdf = reinterpret_cast<uint16_t*>(s_raw);
+  int32_t* s_row = reinterpret_cast<int32_t*>(s_raw + ((size_t)tv.entries * 2 + 15) / 16 * 16);
+  stage_tables(tv, s_cdf, s_row);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * kChunksPerWg + wave;
+  if (c >= n_chunks) return;
+  // words in front of this chunk
+  unsigned long long before = 0;
+  for (int64_t j = lane; j < c; j += kLanes) before += in[kHeaderWords + j];
+  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+  const uint32_t cw = in[kHeaderWords + c];
+  const uint32_t* p = in + kHeaderWords + n_chunks + before;
+  int bad = 0;
+  if (cw < 2 * kLanes) {
+    if (lane == 0) atomicOr(status, 1);
+    return;
+  }
+  uint64_t x = (uint64_t)p[2 * lane] | ((uint64_t)p[2 * lane + 1] << 32);
+  int64_t ptr = 2 * kLanes;
+  const int64_t base = c * kLanes * T;
+
+  auto refill = [&](bool need) {
+    const unsigned long long bal = __ballot(need);
+    const int cnt = __popcll(bal);
+    if (cnt) {
+      if (ptr + cnt > (int64_t)cw) {
+        bad |= 1;
+        if (need) x = kL;   // keep the arithmetic defined; the status word reports the stream
+      } else {
+        if (need) x = (x << 32) | p[ptr + lane_rank(bal)];
+        ptr += cnt;
+      }
+    }
+  };
+
+  for (int64_t t = 0; t < T; ++t) {
+    const int64_t i = base + t * kLanes + lane;
+    const bool act = i < n;
+    int32_t value = 0, max_value = 0, off_sym = 0;
+    bool esc = false;
+    if (act) {
+      const int r = idx ? (int)idx[i] : (int)(i / idx_run);
+      const int off = s_row[3 * r], len = s_row[3 * r + 1];
+      off_sym = s_row[3 * r + 2];
+      max_value = len - 2;
+      const uint32_t cum = (uint32_t)(x & 0xFFFFu);
+      int lo = 0, hi = len - 2;   // largest s with cdf[s] <= cum (cdf[0] = 0)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((uint32_t)s_cdf[off + mid] <= cum) lo = mid;
+        else hi = mid - 1;
+      }
+      const uint32_t c0 = s_cdf[off + lo], c1 = s_cdf[off + lo + 1];
+      uint32_t freq = (c1 - c0) & 0xFFFFu;
+      if (freq == 0) freq = 65536;
+      x = (uint64_t)freq * (x >> 16) + cum - c0;
+      value = lo;
+      esc = lo == max_value;
+    }
+    refill(act && x < kL);
+    if (__ballot(esc) != 0ull) {
+      // bypass rounds: round 1 reads the nibble count, the following rounds the nibbles, least significant first
+      bool in = esc;
+      int remaining = -1, j = 0;
+      uint32_t raw = 0;
+      while (__ballot(in) != 0ull) {
+        uint32_t val = 0;
+        if (in) {
+          val = (uint32_t)(x & 15u);
+          x >>= 4;
+        }
+        refill(in && x < kL);
+        if (in) {
+          if (remaining < 0) {
+            if (val > 8) bad |= 2;   // a 32-bit value has at most 8 nibbles
+            remaining = val > 8 ? 0 : (int)val;
+          } else {
+            raw |= val << (4 * j);
+            ++j;
+            --remaining;
+          }
+          if (remaining == 0) in = false;
+        }
+      }
+      if (esc) {
+        value = (int32_t)(raw >> 1);
+        if (raw & 1u) value = -value - 1;
+        else value += max_value;
+      }
+    }
+    if (act) sym[i] = value + off_sym;
+  }
+  const unsigned long long b1 = __ballot((bad & 1) != 0), b2 = __ballot((bad & 2) != 0);
+  if (lane == 0 && (b1 | b2) != 0ull) atomicOr(status, (b1 ? 1 : 0) | (b2 ? 2 : 0));
+}
+
+// ======================================================================== C-ABI
+static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_row, t->n_cdf, t->entries}; }
+
+extern "C" int pcc_rans_encode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, const int32_t* d_sym, const uint8_t* d_idx,
+                                   int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
+                                   int64_t* h_lens) {
+  PCC_REQUIRE(ctx && tables && d_out && h_lens && n >= 0 && n < ((int64_t)1 << 32) && n_streams >= 1 && n_streams <= 64 &&
+                  cap_each >= 4 * (kHeaderWords + 1 + 2 * kLanes) && cap_each % 4 == 0 && (n == 0 || d_sym) &&
+                  (d_idx || idx_run >= 1),
+              PCC_E_ARG, "pcc_rans_encode_dev: bad argument");
+  PCC_REQUIRE((uintptr_t)d_out % 4 == 0, PCC_E_ARG, "pcc_rans_encode_dev: output must be 4-byte aligned");
+  hipStream_t st = ctx->stream;
+  const int64_t T = steps_for(n), nc = chunks_for(n, T);
+  PccProfScope prof(ctx, "rans_encode_dev", n, n_streams, T, nc);
+  int rc = PCC_OK;
+  // first with room for one word per symbol and a half on top (escapes are rare), then with the worst case
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int64_t cap_words = 2 * kLanes + (attempt == 0 ? kLanes * T * 3 / 2 + 64 : kLanes * T * 11);
+    const size_t work_bytes = (size_t)n_streams * nc * cap_words * 4;
+    PCC_TRY(pcc_arena_reserve(ctx, work_bytes + pcc_align((size_t)n_streams * nc * 4) + pcc_align((size_t)n_streams * 8) + 1024));
+    uint32_t* work = (uint32_t*)pcc_arena_alloc(ctx, work_bytes);
+    uint32_t* words = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n_streams * nc * 4);
+    long long* lens = (long long*)pcc_arena_alloc(ctx, (size_t)n_streams * 8);
+    if (!work || !words || !lens) return PCC_E_NOMEM;
+    hipLaunchKernelGGL(k_rans_enc, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
+                       view_of(tables), d_sym, d_idx, idx_run, n, T, nc, work, cap_words, words);
+    PCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_rans_pack, dim3((unsigned)(nc + 1), n_streams), dim3(256), 0, st, (const uint32_t*)work, cap_words,
+                       (const uint32_t*)words, n, T, nc, d_out, cap_each, lens);
+    PCC_CHECK_LAUNCH();
+    long long* h = (long long*)ctx->pinned;
+    PCC_REQUIRE((size_t)n_streams * 8 <= ctx->pinned_cap, PCC_E_ARG, "pcc_rans_encode_dev: too many streams");
+    PCC_HIP(hipMemcpyAsync(h, lens, (size_t)n_streams * 8, hipMemcpyDeviceToHost, st));
+    PCC_HIP(hipStreamSynchronize(st));
+    rc = PCC_OK;
+    for (int s = 0; s < n_streams; ++s) {
+      h_lens[s] = h[s];
+      if (h[s] < 0) rc = PCC_E_NOMEM;
+    }
+    if (rc == PCC_OK) return PCC_OK;
+  }
+  pcc_set_error("pcc_rans_encode_dev: a stream does not fit %lld bytes", (long long)cap_each);
+  return rc;
+}
+
+extern "C" int pcc_rans_stream_info(const uint8_t* h_in, int64_t len, int64_t* h_n, int64_t* h_steps, int64_t* h_chunks) {
+  PCC_REQUIRE(h_in && len >= 4 * kHeaderWords, PCC_E_STREAM, "interleaved rANS stream: shorter than its header");
+  uint32_t w[4];
+  memcpy(w, h_in, 16);
+  const int64_t n = w[1], T = w[2], nc = w[3];
+  PCC_REQUIRE(w[0] == kMagic, PCC_E_STREAM, "interleaved rANS stream: bad magic");
+  PCC_REQUIRE(T >= 1 && T <= 65536 && nc >= 1 && nc <= ((int64_t)1 << 24) && (int64_t)kLanes * T * nc >= n &&
+                  (int64_t)kLanes * T * (nc - 1) < std::max<int64_t>(n, 1),
+              PCC_E_STREAM, "interleaved rANS stream: %lld symbols in %lld chunks of 64 x %lld", (long long)n, (long long)nc,
+              (long long)T);
+  PCC_REQUIRE(len >= 4 * (kHeaderWords + nc), PCC_E_STREAM, "interleaved rANS stream: truncated chunk table");
+  int64_t total = kHeaderWords + nc;
+  for (int64_t c = 0; c < nc; ++c) {
+    uint32_t cw;
+    memcpy(&cw, h_in + 4 * (kHeaderWords + c), 4);
+    PCC_REQUIRE(cw >= 2 * kLanes, PCC_E_STREAM, "interleaved rANS stream: chunk %lld has no states", (long long)c);
+    total += cw;
+  }
+  PCC_REQUIRE(total * 4 == len, PCC_E_STREAM, "interleaved rANS stream: chunks take %lld bytes, stream has %lld",
+              (long long)(total * 4), (long long)len);
+  if (h_n) *h_n = n;
+  if (h_steps) *h_steps = T;
+  if (h_chunks) *h_chunks = nc;
+  return PCC_OK;
+}
+
+extern "C" int pcc_rans_decode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, const uint8_t* d_in, int64_t len,
+                                   int64_t n, int64_t steps, int64_t n_chunks, const uint8_t* d_idx, int64_t idx_run,
+                                   int32_t* d_sym, int32_t* d_status) {
+  PCC_REQUIRE(ctx && tables && d_in && d_status && n >= 0 && (n == 0 || d_sym) && (d_idx || idx_run >= 1) && steps >= 1 &&
+                  n_chunks >= 1 && len >= 4 * (kHeaderWords + n_chunks) && (int64_t)kLanes * steps * n_chunks >= n,
+              PCC_E_ARG, "pcc_rans_decode_dev: bad argument");
+  PCC_REQUIRE((uintptr_t)d_in % 4 == 0, PCC_E_ARG, "pcc_rans_decode_dev: stream must be 4-byte aligned");
+  PccProfScope prof(ctx, "rans_decode_dev", n, 1, steps, n_chunks);
+  hipLaunchKernelGGL(k_rans_dec, dim3(nblk(n_chunks, kChunksPerWg)), dim3(256), tables->lds_bytes(), ctx->stream,
+                     view_of(tables), (const uint32_t*)d_in, d_idx, idx_run, n, steps, n_chunks, d_sym, d_status);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}

@@ -503,6 +503,68 @@ class Runtime:
         return occ[:sum(ln)], ln
 
 
+# ---------------------------------------------------------------- GPU coder (container version 1)
+class RansDev:
+    """a CDF set in HBM for the interleaved rANS coder on the GPU (pcc_rans_dev_*, csrc/rans_gpu.hip)"""
+
+    def __init__(self, cdfs, sizes, offsets):
+        self.lib = _abi.lib()
+        cdfs = np.ascontiguousarray(cdfs, dtype=np.int32)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        self.handle = self.lib.pcc_rans_dev_create(_np_ptr(cdfs), cdfs.shape[1], _np_ptr(sizes), _np_ptr(offsets),
+                                                   cdfs.shape[0])
+        if not self.handle:
+            raise PccError(-1, "pcc_rans_dev_create", self.lib.pcc_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pcc_rans_dev_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, rt, sym, idx=None, idx_run=1):
+        """sym: int32 device tensor [S, n]; idx: uint8 device tensor [S, n] or None (table = position // idx_run).
+        Returns the S streams as bytes."""
+        assert sym.is_cuda and sym.dtype == torch.int32 and sym.dim() == 2 and sym.is_contiguous()
+        s, n = sym.shape
+        if idx is not None:
+            assert idx.is_cuda and idx.dtype == torch.uint8 and idx.shape == sym.shape and idx.is_contiguous()
+        cap = (int(self.lib.pcc_rans_dev_bound(n)) + 3) // 4 * 4
+        cap = min(cap, 4 * (4 + n + 4096 + 130 * (n // 32768 + 1)) * 3)     # generous; the call reports if it is not
+        out = rt.empty((s, cap), torch.uint8)
+        lens = (C.c_int64 * s)()
+        check(self.lib.pcc_rans_encode_dev(rt.ctx, self.handle, _ptr(sym), _ptr(idx) if idx is not None else None,
+                                           idx_run, n, s, _ptr(out), cap, lens), "pcc_rans_encode_dev")
+        host = out.cpu().numpy()
+        return [host[i, :lens[i]].tobytes() for i in range(s)]
+
+    def decode(self, rt, data, n, idx=None, idx_run=1):
+        """data: bytes of one stream; returns the int32 device tensor [n] (raises on a malformed stream)"""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        hn, ht, hc = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.pcc_rans_stream_info(_np_ptr(buf), buf.shape[0], C.byref(hn), C.byref(ht), C.byref(hc)),
+              "pcc_rans_stream_info")
+        if hn.value != n:
+            raise PccError(-5, "RansDev.decode", f"stream holds {hn.value} symbols, {n} expected")
+        d_in = rt.to_device(buf.copy())
+        sym = rt.empty((n,), torch.int32)
+        status = torch.zeros(1, dtype=torch.int32, device=sym.device)
+        check(self.lib.pcc_rans_decode_dev(rt.ctx, self.handle, _ptr(d_in), buf.shape[0], n, ht.value, hc.value,
+                                           _ptr(idx) if idx is not None else None, idx_run, _ptr(sym), _ptr(status)),
+              "pcc_rans_decode_dev")
+        rt.sync()
+        st = int(status.item())
+        if st:
+            raise PccError(-5, "pcc_rans_decode_dev", f"malformed interleaved rANS stream (status {st})")
+        return sym
+
+
 # ---------------------------------------------------------------- host coders (no ctx)
 def rans_encode_multi(sym, idx, cdfs, sizes, offsets):
     """sym/idx: numpy [S, n], either (int32, int32) or the compact (int16, uint8);

@@ -392,6 +392,43 @@ int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx,
                      const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
                      int32_t* h_sym);
 
+/* ---- range-ANS on the GPU: container version 1 (flagged extension) ------ */
+
+/* Same call sites as the host coders above (codec_pipeline.py:305-306,426-430;
+ * codec_parallel.py:307,398-400), different stream: the symbols of an array are
+ * dealt to 64 rANS states per wave (csrc/rans_gpu.hip gives the layout), so the
+ * coder runs on the device next to the kernels that make / consume the symbols
+ * and the step has no serial host coder on its critical path.  The arithmetic of
+ * a coding step (64-bit state, 16-bit CDFs, escape + 4-bit bypass) is that of
+ * the reference's coder; a container whose y / z strings have this form carries
+ * PCC_CONTAINER_V1 in the top byte of its first word (codec.hip) — the reference
+ * decoder cannot read it, this library's decoders read both versions.
+ *   tables : the CDF set in HBM (the arguments of pcc_rans_encode), made once
+ *   d_sym  : int32 [n_streams, n]; d_idx uint8 [n_streams, n] table index per
+ *            symbol, or NULL: index = position / idx_run (channel-major arrays)
+ *   d_out  : n_streams streams at d_out + s * cap_each (device, 4-byte aligned);
+ *            pcc_rans_dev_bound(n) bytes always suffice; h_lens[s] = bytes
+ * encode synchronises the stream once (the lengths); decode does not: it takes
+ * the header fields pcc_rans_stream_info checked on the host copy of the stream
+ * and ORs d_status (int32, device) with 1 / 2 if a chunk runs out of words / an
+ * escape is malformed — test it after the next synchronisation. */
+typedef struct pcc_rans_dev pcc_rans_dev;
+pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitch,
+                                  const int32_t* h_sizes, const int32_t* h_offsets,
+                                  int n_cdf);
+void pcc_rans_dev_destroy(pcc_rans_dev* tables);
+int64_t pcc_rans_dev_bound(int64_t n);
+int pcc_rans_encode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables,
+                        const int32_t* d_sym, const uint8_t* d_idx, int64_t idx_run,
+                        int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
+                        int64_t* h_lens);
+int pcc_rans_stream_info(const uint8_t* h_in, int64_t len, int64_t* h_n,
+                         int64_t* h_steps, int64_t* h_chunks);
+int pcc_rans_decode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, const uint8_t* d_in,
+                        int64_t len, int64_t n, int64_t steps, int64_t n_chunks,
+                        const uint8_t* d_idx, int64_t idx_run, int32_t* d_sym,
+                        int32_t* d_status);
+
 /* replaces: utils.gpcc_encode / gpcc_decode (shared/utils.py:169-240), i.e.
  * the tmc3 subprocess: lossless octree occupancy coding of one frame's latent
  * coordinates.  The blob is opaque to the container (length-prefixed slot) and

@@ -221,6 +221,34 @@ class Oracle:
         assert r == 0, r
         return sym
 
+    # ------------------------------------------------------------ container version 1: interleaved rANS
+    def rans_interleaved_encode(self, sym, idx, which, idx_run=1):
+        """idx: uint8 array or None (table of symbol i = i // idx_run)"""
+        cdf, sizes, offs = self._tables(which)
+        sym = np.ascontiguousarray(sym, dtype=np.int32).reshape(-1)
+        n = sym.shape[0]
+        idx8 = None if idx is None else np.ascontiguousarray(idx, dtype=np.uint8).reshape(-1)
+        cap = 48 * n + 4096
+        out = np.empty(cap, dtype=np.uint8)
+        self.lib.orc_rans_interleaved_encode.restype = C.c_int64
+        got = self.lib.orc_rans_interleaved_encode(_p(sym), _p(idx8) if idx8 is not None else None, C.c_int64(idx_run),
+                                                   C.c_int64(n), _p(cdf), C.c_int(cdf.shape[1]), _p(sizes), _p(offs),
+                                                   _p(out), C.c_int64(cap))
+        assert got >= 0
+        return out[:got].tobytes()
+
+    def rans_interleaved_decode(self, data, idx, n, which, idx_run=1):
+        cdf, sizes, offs = self._tables(which)
+        idx8 = None if idx is None else np.ascontiguousarray(idx, dtype=np.uint8).reshape(-1)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        sym = np.empty(n, dtype=np.int32)
+        r = self.lib.orc_rans_interleaved_decode(_p(buf), C.c_int64(buf.shape[0]), _p(idx8) if idx8 is not None else None,
+                                                 C.c_int64(idx_run), C.c_int64(n), _p(cdf), C.c_int(cdf.shape[1]),
+                                                 _p(sizes), _p(offs), _p(sym))
+        if r != 0:
+            raise ValueError(f"interleaved rANS stream: decode error {r}")
+        return sym
+
     def octree_encode(self, points, bias):
         points = np.ascontiguousarray(points, dtype=np.int32)
         cap = 64 + 16 * points.shape[0] * 2 + 64
