@@ -39,6 +39,7 @@ PROTOTYPES = {
     "pcc_codec_create": (vp, [vp, C.c_size_t, i32, vp]),
     "pcc_codec_destroy": (None, [vp]),
     "pcc_codec_ctx": (vp, [vp]),
+    "pcc_codec_set_container_version": (i32, [vp, i32]),
     "pcc_encode_gop": (i32, [vp, vp, vp, i64, i32, C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64,
                              C.POINTER(C.c_double)]),
     "pcc_encode_gop_frames": (i32, [vp, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p), i32, pi64, i32,
@@ -47,6 +48,7 @@ PROTOTYPES = {
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
     "pcc_decode_fetch_packed": (i32, [vp, vp, vp]),
     "pcc_sparse_conv_head_up": (i32, [vp, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp, vp]),
+    "pcc_gaussian_quant_dev": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "pcc_rans_dev_create": (vp, [vp, i32, vp, vp, i32]),
     "pcc_rans_dev_destroy": (None, [vp]),
     "pcc_rans_dev_bound": (i64, [i64]),

@@ -54,8 +54,15 @@ def _to_dev_as_is(a, keep, other, device):
 
 
 class CompressionPipeline:
-    def __init__(self, settings, device=0, slots=3, stage_sync=None, engine=None):
+    def __init__(self, settings, device=0, slots=3, stage_sync=None, engine=None, container_version=None):
         self.device = torch.device("cuda", device)
+        # 0 (default): the reference's container, y / z strings coded by the host coder in CompressAI's format;
+        # 1 (or PCC_CONTAINER_VERSION=1): flagged extension, y / z strings in the GPU coder's interleaved form
+        # (csrc/rans_gpu.hip) — read by this package's decoders only
+        self.container_version = int(os.environ.get("PCC_CONTAINER_VERSION", "0")) if container_version is None \
+            else int(container_version)
+        if self.container_version not in (0, 1):
+            raise ValueError(f"container_version must be 0 or 1, got {self.container_version}")
         self.engine = engine or os.environ.get("PCC_ENGINE", "native")
         if self.engine not in ("native", "ops"):
             raise ValueError(f"engine must be 'native' or 'ops', got {self.engine!r}")
@@ -68,7 +75,8 @@ class CompressionPipeline:
         self.compression_model = self.load_model(base_path)
         self._slots = queue.Queue()
         if self.engine == "native":
-            self.codecs = [NativeCodec(self.compression_model.tensors, device) for _ in range(slots)]
+            self.codecs = [NativeCodec(self.compression_model.tensors, device, self.container_version)
+                           for _ in range(slots)]
             self.runtimes = [c.rt for c in self.codecs]
             for c in self.codecs:
                 self._slots.put(c)

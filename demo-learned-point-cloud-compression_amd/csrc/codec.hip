@@ -245,6 +245,11 @@ struct pcc_codec {
   std::map<std::string, float*> dev;  // weights / biases / tables in HBM
   int c_y = 32, c_z = 32;
   PccRansTables* gc_tables = nullptr;  // coder tables of the Gaussian CDFs, built once (rans_gate.h)
+  // container version written by pcc_encode_gop* (pcc_codec_set_container_version): 0 = the reference's layout, y and z
+  // strings single rANS streams coded on the host; 1 = flagged extension, y and z strings wave-interleaved streams
+  // coded on the GPU (rans_gpu.hip).  The decoder reads the version from the container.
+  int container_version = 0;
+  pcc_rans_dev *gc_dev = nullptr, *eb_dev = nullptr;  // the two CDF sets in HBM for the GPU coder
   PccWorkers workers;                  // the Q coder threads of the encoder
   DevPool pool;
   Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec;
@@ -777,8 +782,23 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
       delete cd;
       return nullptr;
     }
+    const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
+                 *eb_off = find(cd, "entropy_bottleneck.offset");
+    cd->gc_dev = pcc_rans_dev_create(gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0]);
+    if (eb_cdf && eb_len && eb_off)
+      cd->eb_dev = pcc_rans_dev_create(eb_cdf->i32(), (int)eb_cdf->dims[1], eb_len->i32(), eb_off->i32(), (int)eb_cdf->dims[0]);
+    // (a table set too large for the coder's LDS image leaves the pointer null: version 1 is then refused, not faked)
   }
   return cd;
+}
+
+extern "C" int pcc_codec_set_container_version(pcc_codec* cd, int version) {
+  PCC_REQUIRE(cd, PCC_E_ARG, "pcc_codec_set_container_version: null codec");
+  PCC_REQUIRE(version == 0 || version == 1, PCC_E_ARG, "pcc_codec_set_container_version: version %d (0 or 1)", version);
+  PCC_REQUIRE(version == 0 || (cd->gc_dev && cd->eb_dev), PCC_E_ARG,
+              "pcc_codec_set_container_version: the checkpoint's CDF tables have no device form");
+  cd->container_version = version;
+  return PCC_OK;
 }
 
 extern "C" void pcc_codec_destroy(pcc_codec* cd) {
@@ -786,6 +806,8 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
   if (cd->ctx) (void)pcc_sync(cd->ctx);
   for (auto& kv : cd->dev) (void)hipFree(kv.second);
   pcc_rans_tables_free(cd->gc_tables);
+  pcc_rans_dev_destroy(cd->gc_dev);
+  pcc_rans_dev_destroy(cd->eb_dev);
   cd->pool.release();
   for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec})
     p->release();
@@ -999,15 +1021,18 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   View zv;
   PCC_TRY(view_of(cd, z.cs, &zv));
   Feat z_hat;
+  const bool v1 = cd->container_version == 1;  // y / z strings coded on the GPU (rans_gpu.hip), flagged container
+  int32_t* zsym_dev = nullptr;
   {
     CODEC_ALLOC(zs_f, float, std::max<int64_t>(nz, 1) * cz);
     CODEC_ALLOC(zsym, int32_t, std::max<int64_t>(nz, 1) * cz);
     CODEC_ALLOC(zhat_rows, float, std::max<int64_t>(nz, 1) * cz);
+    zsym_dev = zsym;
     PCC_TRY(cd->pin_zsym.ensure((size_t)std::max<int64_t>(nz, 1) * cz * 4));
     if (nz > 0) {
       PCC_TRY(pcc_gather_rows(ctx, z.f, zv.perm, nz, 4 * cz, zs_f));
       PCC_TRY(pcc_factorized_quant(ctx, zs_f, nz, cz, cd->dev["entropy_bottleneck.medians"], zsym, zhat_rows));
-      PCC_HIP(hipMemcpyAsync(cd->pin_zsym.p, zsym, (size_t)nz * cz * 4, hipMemcpyDeviceToHost, st));
+      if (!v1) PCC_HIP(hipMemcpyAsync(cd->pin_zsym.p, zsym, (size_t)nz * cz * 4, hipMemcpyDeviceToHost, st));
     }
     float* zf;
     PCC_TRY(rows_to_tensor(cd, zv, zhat_rows, cz, &zf));
@@ -1020,9 +1045,9 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
                *eb_off = find(cd, "entropy_bottleneck.offset");
   PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_encode_gop: entropy_bottleneck tables missing");
-  auto side_streams = [&]() -> int {
+  auto geometry_slots = [&]() -> int {
     PCC_TRY(geometry_device_half());
-    double t = now_s();
+    const double t = now_s();
     for (int f = 0; f < n_frames; ++f) {
       const FrameGeo& g = geo[f];
       const int64_t cap = 64 + 2 * g.occ_len + 16;
@@ -1034,7 +1059,11 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       blobs[f].resize((size_t)len);
     }
     helper_geo_s = now_s() - t;
-    t = now_s();
+    return PCC_OK;
+  };
+  auto side_streams = [&]() -> int {
+    PCC_TRY(geometry_slots());
+    double t = now_s();
     std::vector<int32_t> idx((size_t)nz * cz);
     for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz, idx.begin() + (size_t)(c + 1) * nz, c);
     PCC_TRY(rans_encode_grow((const int32_t*)cd->pin_zsym.p, idx.data(), nz * cz, eb_cdf, eb_len, eb_off, &z_string));
@@ -1053,7 +1082,63 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   t0 = now_s();
   std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);  // only the int16-overflow path below fills these
   std::vector<uint8_t> head_done((size_t)n_q, 0);
-  {
+  if (v1) {
+    // Container version 1: symbols and indexes stay in HBM, the Q y streams and the z stream are coded by the GPU's
+    // interleaved coder behind the quantiser, and only the finished streams cross PCIe.  The geometry slots (device
+    // half + host occupancy coder) follow in the stream / on this thread as in version 0.
+    PCC_REQUIRE(cd->gc_dev && cd->eb_dev, PCC_E_ARG, "pcc_encode_gop: container version 1 without device CDF tables");
+    float* params;
+    PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
+    std::vector<float> scale_h((size_t)n_q * cy);
+    for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &scale_h[(size_t)q * cy]));
+    CODEC_ALLOC(scale_d, float, n_q * cy);
+    PCC_HIP(hipMemcpyAsync(scale_d, scale_h.data(), scale_h.size() * 4, hipMemcpyHostToDevice, st));
+    const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
+    PCC_REQUIRE(tab, PCC_E_ARG, "pcc_encode_gop: gaussian_conditional tables missing");
+    const int64_t per = (int64_t)cy * ny, tot = per * n_q, nzs = (int64_t)cz * nz;
+    CODEC_ALLOC(sym32, int32_t, std::max<int64_t>(tot, 1));
+    CODEC_ALLOC(idx8, uint8_t, std::max<int64_t>(tot, 1));
+    if (ny > 0)
+      PCC_TRY(pcc_gaussian_quant_dev(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
+                                     (int)tab->dims[0], sym32, idx8));
+    CODEC_ALLOC(d_lens, long long, n_q + 1);
+    PCC_TRY(cd->pin_flag.ensure(8 * 65 + 64));
+    long long* h_lens = (long long*)cd->pin_flag.p;
+    uint8_t *ystreams = nullptr, *zstream = nullptr;
+    int64_t cap_y = 0, cap_z = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      // attempt 0: 6 bytes per symbol of room (the coder's own first attempt holds 1.5 words per symbol); attempt 1: the bound
+      cap_y = attempt == 0 ? std::min<int64_t>(pcc_rans_dev_bound(per), (6 * per + 65536) / 4 * 4) : pcc_rans_dev_bound(per);
+      cap_z = attempt == 0 ? std::min<int64_t>(pcc_rans_dev_bound(nzs), (6 * nzs + 65536) / 4 * 4) : pcc_rans_dev_bound(nzs);
+      ystreams = (uint8_t*)cd->pool.alloc((size_t)cap_y * n_q);
+      zstream = (uint8_t*)cd->pool.alloc((size_t)cap_z);
+      if (!ystreams || !zstream) return PCC_E_NOMEM;
+      PCC_TRY(pcc_rans_encode_dev_async(ctx, cd->gc_dev, sym32, idx8, 1, per, n_q, ystreams, cap_y, d_lens, attempt));
+      PCC_TRY(pcc_rans_encode_dev_async(ctx, cd->eb_dev, zsym_dev, nullptr, std::max<int64_t>(nz, 1), nzs, 1, zstream, cap_z,
+                                        d_lens + n_q, attempt));
+      PCC_HIP(hipMemcpyAsync(h_lens, d_lens, (size_t)(n_q + 1) * 8, hipMemcpyDeviceToHost, st));
+      if (attempt == 0) PCC_TRY(geometry_slots());   // its synchronisation also lands the lengths
+      else PCC_HIP(hipStreamSynchronize(st));
+      bool fits = true;
+      for (int q = 0; q <= n_q; ++q) fits &= h_lens[q] >= 0;
+      if (fits) break;
+      PCC_REQUIRE(attempt == 0, PCC_E_NOMEM, "pcc_encode_gop: a coded stream exceeds its bound");
+    }
+    int64_t total = 0;
+    for (int q = 0; q <= n_q; ++q) total += (h_lens[q] + 255) & ~(long long)255;
+    PCC_TRY(cd->pin_ysym.ensure((size_t)std::max<int64_t>(total, 1)));
+    std::vector<int64_t> at((size_t)n_q + 1);
+    int64_t pos = 0;
+    for (int q = 0; q <= n_q; ++q) {
+      at[q] = pos;
+      const uint8_t* src = q < n_q ? ystreams + (size_t)q * cap_y : zstream;
+      PCC_HIP(hipMemcpyAsync(cd->pin_ysym.p + pos, src, (size_t)h_lens[q], hipMemcpyDeviceToHost, st));
+      pos += (h_lens[q] + 255) & ~(long long)255;
+    }
+    PCC_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < n_q; ++q) y_strings[q].assign(cd->pin_ysym.p + at[q], cd->pin_ysym.p + at[q] + h_lens[q]);
+    z_string.assign(cd->pin_ysym.p + at[n_q], cd->pin_ysym.p + at[n_q] + h_lens[n_q]);
+  } else {
     float* params;
     PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
     std::vector<float> scale_h((size_t)n_q * cy);
@@ -1211,7 +1296,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       o[32] = (uint8_t)(lz >> 24); o[33] = (uint8_t)(lz >> 16); o[34] = (uint8_t)(lz >> 8); o[35] = (uint8_t)lz;
     } else {
       o.clear();
-      put_be32(o, n_frames);
+      put_be32(o, n_frames | (cd->container_version << 24));
       put_be_f64(o, h_q[2 * q]);
       put_be_f64(o, h_q[2 * q + 1]);
       put_be32(o, (int32_t)ny);
@@ -1253,7 +1338,15 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   // ---- step 1: container (codec_parallel.py:173-216)
   double t0 = now_s();
   Reader r{h_in, len};
-  const int32_t n_frames = r.be32();
+  // first word: frame count, with the container version in its top byte (0 = the reference's layout; 1 = y / z strings
+  // in the GPU coder's interleaved form, rans_gpu.hip)
+  const int32_t word0 = r.be32();
+  const int version = (int)(((uint32_t)word0 >> 24) & 0xFFu);
+  const int32_t n_frames = (int32_t)((uint32_t)word0 & 0x00FFFFFFu);
+  PCC_REQUIRE(version == 0 || version == 1, PCC_E_STREAM, "pcc_decode_gop: container version %d", version);
+  const bool v1 = version == 1;
+  PCC_REQUIRE(!v1 || (cd->gc_dev && cd->eb_dev), PCC_E_ARG, "pcc_decode_gop: version-1 container, but the checkpoint's CDF "
+              "tables have no device form");
   const double qg = r.be_f64(), qa = r.be_f64();
   const int32_t ny_hdr = r.be32(), nz_hdr = r.be32(), ylen = r.be32(), zlen = r.be32();
   const uint8_t* ystr = r.bytes(ylen);
@@ -1332,8 +1425,26 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   };
   // N_z is still only an announced number here.  Up to kEarlyZSymbols symbols (16 MB of buffers) the job starts at once
   // and overlaps the geometry decode; a container announcing more waits until the geometry streams have confirmed N_y.
-  const bool z_early = (int64_t)nz_hdr * cz <= kEarlyZSymbols;
+  const bool z_early = !v1 && (int64_t)nz_hdr * cz <= kEarlyZSymbols;
   if (z_early) start_z_job();
+  // version 1: the streams are decoded on the device; their headers are checked here, on the host copy
+  int64_t z_steps = 0, z_chunks = 0, y_steps = 0, y_chunks = 0;
+  int32_t* d_status = nullptr;
+  if (v1) {
+    int64_t zn = 0, yn = 0;
+    PCC_TRY(pcc_rans_stream_info(zstr, zlen, &zn, &z_steps, &z_chunks));
+    PCC_TRY(pcc_rans_stream_info(ystr, ylen, &yn, &y_steps, &y_chunks));
+    PCC_REQUIRE(zn == (int64_t)nz_hdr * cz && yn == (int64_t)ny_hdr * cy, PCC_E_STREAM,
+                "pcc_decode_gop: streams hold %lld / %lld symbols, header says %lld / %lld", (long long)yn, (long long)zn,
+                (long long)ny_hdr * cy, (long long)nz_hdr * cz);
+    d_status = (int32_t*)cd->pool.alloc(4);
+    if (!d_status) return PCC_E_NOMEM;
+    PCC_HIP(hipMemsetAsync(d_status, 0, 4, st));
+    // both strings go up now, through pinned memory, behind nothing
+    PCC_TRY(cd->pin_dec.ensure((size_t)ylen + (size_t)zlen + 512));
+    memcpy(cd->pin_dec.p, zstr, (size_t)zlen);
+    memcpy(cd->pin_dec.p + (((size_t)zlen + 255) & ~(size_t)255), ystr, (size_t)ylen);
+  }
 
   // ---- step 2: latent coordinates of every frame (codec_parallel.py:266-289)
   t0 = now_s();
@@ -1357,7 +1468,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     n32 += depth >= 2 ? level_n[depth - 2] : 1;
     n_batch = f + 1;
   }
-  if (!z_early) start_z_job();
+  if (!z_early && !v1) start_z_job();
   PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
   int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
   bool out_of_range = false;
@@ -1411,11 +1522,20 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     return z_rc;
   }
   Feat z_hat;
+  uint8_t* d_ystr = nullptr;
   {
     const int64_t nz = zcs->n;
     CODEC_ALLOC(zsym_d, int32_t, std::max<int64_t>(nz, 1) * cz);
     CODEC_ALLOC(rows, float, std::max<int64_t>(nz, 1) * cz);
-    if (nz > 0) {
+    if (v1) {
+      const size_t zpad = ((size_t)zlen + 255) & ~(size_t)255;
+      CODEC_ALLOC(d_str, uint8_t, zpad + (size_t)ylen + 256);
+      PCC_HIP(hipMemcpyAsync(d_str, cd->pin_dec.p, zpad + (size_t)ylen, hipMemcpyHostToDevice, st));
+      d_ystr = d_str + zpad;
+      PCC_TRY(pcc_rans_decode_dev(ctx, cd->eb_dev, d_str, zlen, nz * cz, z_steps, z_chunks, nullptr, std::max<int64_t>(nz, 1),
+                                  zsym_d, d_status));
+      if (nz > 0) PCC_TRY(pcc_factorized_dequant(ctx, zsym_d, nz, cz, cd->dev["entropy_bottleneck.medians"], rows));
+    } else if (nz > 0) {
       PCC_TRY(cd->pin_zsym.ensure((size_t)nz * cz * 4));
       memcpy(cd->pin_zsym.p, zsym.data(), (size_t)nz * cz * 4);
       PCC_HIP(hipMemcpyAsync(zsym_d, cd->pin_zsym.p, (size_t)nz * cz * 4, hipMemcpyHostToDevice, st));
@@ -1454,7 +1574,13 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     CODEC_ALLOC(idx8, uint8_t, std::max<int64_t>(tot, 1));
     CODEC_ALLOC(sym_d, int32_t, std::max<int64_t>(tot, 1));
     CODEC_ALLOC(rows, float, std::max<int64_t>(tot, 1));
-    if (ny > 0) {
+    if (ny > 0 && v1) {
+      // version 1: indexes, stream and symbols never leave the device, and the host does not wait for anything here
+      PCC_TRY(pcc_gaussian_indexes8(ctx, params, ny, cy, scale_d, cd->dev["gaussian_conditional.scale_table"],
+                                    (int)tab->dims[0], idx8));
+      PCC_TRY(pcc_rans_decode_dev(ctx, cd->gc_dev, d_ystr, ylen, tot, y_steps, y_chunks, idx8, 1, sym_d, d_status));
+      PCC_TRY(pcc_gaussian_dequant(ctx, sym_d, params, ny, cy, scale_d, tab->f32()[0], ab->f32()[0], ab->f32()[1], rows));
+    } else if (ny > 0) {
       PCC_TRY(pcc_gaussian_indexes8(ctx, params, ny, cy, scale_d, cd->dev["gaussian_conditional.scale_table"],
                                     (int)tab->dims[0], idx8));
       PCC_TRY(cd->pin_yidx.ensure((size_t)tot));
@@ -1584,7 +1710,17 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     cd->rec_n = nr;
     cd->rec_offsets = h.cs->offsets;
   }
+  if (v1) {
+    PCC_TRY(cd->pin_flag.ensure(64));
+    PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, d_status, 4, hipMemcpyDeviceToHost, st));
+  }
   PCC_TRY(pcc_sync(ctx));
+  if (v1 && *(volatile int32_t*)cd->pin_flag.p != 0) {
+    cd->rec_n = 0;
+    cd->rec_offsets.clear();
+    pcc_set_error("pcc_decode_gop: malformed interleaved rANS stream (status %d)", *(int32_t*)cd->pin_flag.p);
+    return PCC_E_STREAM;
+  }
   ts[5] = now_s() - t0;
 
   h_info->n_points = cd->rec_n;

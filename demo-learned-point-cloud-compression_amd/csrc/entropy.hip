@@ -97,6 +97,29 @@ __global__ __launch_bounds__(256) void k_gaussian_quant16(
   if (over) atomicOr(flag, 1);
 }
 
+// int32 symbols / uint8 indexes: what the GPU coder reads (rans_gpu.hip); no overflow case
+__global__ __launch_bounds__(256) void k_gaussian_quant_dev(
+    const float* __restrict__ y, const float* __restrict__ params, int64_t n, int c,
+    const float* __restrict__ scale, int nq, const float* __restrict__ table, int n_tab,
+    int32_t* __restrict__ sym, uint8_t* __restrict__ idx) {
+  __shared__ float tab[64];
+  if (threadIdx.x < n_tab) tab[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  const int ch = (int)(t / n);
+  const int64_t i = t - (int64_t)ch * n;
+  const float yv = y[i * c + ch];
+  const float sc = params[i * 2 * c + ch];
+  const float mu = params[i * 2 * c + c + ch];
+  for (int q = 0; q < nq; ++q) {
+    const float s = scale[q * c + ch];
+    const float v = __fsub_rn(__fmul_rn(yv, s), __fmul_rn(mu, s));
+    sym[(int64_t)q * n * c + t] = (int32_t)rintf(v);
+    idx[(int64_t)q * n * c + t] = (uint8_t)scale_index(__fmul_rn(sc, s), tab, n_tab);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gaussian_indexes8(const float* __restrict__ params, int64_t n,
                                                            int c, const float* __restrict__ scale,
                                                            const float* __restrict__ table, int n_tab,
@@ -235,6 +258,19 @@ extern "C" int pcc_gaussian_quant16(pcc_ctx* ctx, const float* d_y, const float*
               "pcc_gaussian_quant16: null buffers");
   hipLaunchKernelGGL(k_gaussian_quant16, dim3(nblk(n * c, 256)), dim3(256), 0, ctx->stream, d_y, d_params,
                      n, c, d_scale, q, d_table, n_tab, d_sym, d_idx, d_flag);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_gaussian_quant_dev(pcc_ctx* ctx, const float* d_y, const float* d_params, int64_t n, int c,
+                                      const float* d_scale, int q, const float* d_table, int n_tab, int32_t* d_sym,
+                                      uint8_t* d_idx) {
+  PCC_REQUIRE(ctx && c >= 1 && q >= 1 && n_tab >= 2 && n_tab <= 64, PCC_E_ARG,
+              "pcc_gaussian_quant_dev: bad arg (c=%d q=%d n_tab=%d)", c, q, n_tab);
+  if (n <= 0) return PCC_OK;
+  PCC_REQUIRE(d_y && d_params && d_scale && d_table && d_sym && d_idx, PCC_E_ARG, "pcc_gaussian_quant_dev: null buffers");
+  hipLaunchKernelGGL(k_gaussian_quant_dev, dim3(nblk(n * c, 256)), dim3(256), 0, ctx->stream, d_y, d_params, n, c,
+                     d_scale, q, d_table, n_tab, d_sym, d_idx);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -34,3 +34,10 @@ int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_id
 // octree_host.cpp: pcc_octree_unpack_levels into a vector that is sized by what the stream actually DECODED, not by
 // the point count its header announces (decoders of untrusted containers; h_level_n needs 16 entries).
 int pcc_octree_unpack_vec(const uint8_t* h_in, int64_t len, std::vector<int32_t>* pts, int64_t* h_level_n);
+
+// rans_gpu.hip: pcc_rans_encode_dev without its read-back (see there)
+struct pcc_ctx;
+struct pcc_rans_dev;
+int pcc_rans_encode_dev_async(pcc_ctx* ctx, const pcc_rans_dev* tables, const int32_t* d_sym, const uint8_t* d_idx,
+                              int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
+                              long long* d_lens, int attempt);

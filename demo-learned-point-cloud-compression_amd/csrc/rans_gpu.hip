@@ -132,6 +132,8 @@ __device__ __forceinline__ int lane_rank(unsigned long long bal) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
 
+static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_row, t->n_cdf, t->entries}; }
+
 // ---- encoder -----------------------------------------------------------------------------------------------------
 // One wave per chunk.  work: per stream and chunk a private buffer of cap_words; the chunk ends at the buffer's end.
 // words_out[s * n_chunks + c] = words of the chunk (0xFFFFFFFF: the buffer was too small).
@@ -382,12 +384,15 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
 }
 
 // ======================================================================== C-ABI
-static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_row, t->n_cdf, t->entries}; }
 
-extern "C" int pcc_rans_encode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, const int32_t* d_sym, const uint8_t* d_idx,
-                                   int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
-                                   int64_t* h_lens) {
-  PCC_REQUIRE(ctx && tables && d_out && h_lens && n >= 0 && n < ((int64_t)1 << 32) && n_streams >= 1 && n_streams <= 64 &&
+// internal (rans_gate.h): the two launches without the read-back.  d_lens (device, int64 [n_streams]) receives the
+// stream lengths, -1 for a stream that did not fit (attempt 0: room for 1.5 words per symbol — escapes are rare;
+// attempt 1: the worst case).  The scratch of a call lives in the ctx arena: valid until the next call on this ctx,
+// which the stream orders behind this one.
+int pcc_rans_encode_dev_async(pcc_ctx* ctx, const pcc_rans_dev* tables, const int32_t* d_sym, const uint8_t* d_idx,
+                              int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
+                              long long* d_lens, int attempt) {
+  PCC_REQUIRE(ctx && tables && d_out && d_lens && n >= 0 && n < ((int64_t)1 << 32) && n_streams >= 1 && n_streams <= 64 &&
                   cap_each >= 4 * (kHeaderWords + 1 + 2 * kLanes) && cap_each % 4 == 0 && (n == 0 || d_sym) &&
                   (d_idx || idx_run >= 1),
               PCC_E_ARG, "pcc_rans_encode_dev: bad argument");
@@ -395,34 +400,47 @@ extern "C" int pcc_rans_encode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, con
   hipStream_t st = ctx->stream;
   const int64_t T = steps_for(n), nc = chunks_for(n, T);
   PccProfScope prof(ctx, "rans_encode_dev", n, n_streams, T, nc);
+  const int64_t cap_words = 2 * kLanes + (attempt == 0 ? kLanes * T * 3 / 2 + 64 : kLanes * T * 11);
+  const size_t work_bytes = (size_t)n_streams * nc * cap_words * 4;
+  PCC_TRY(pcc_arena_reserve(ctx, work_bytes + pcc_align((size_t)n_streams * nc * 4) + 1024));
+  uint32_t* work = (uint32_t*)pcc_arena_alloc(ctx, work_bytes);
+  uint32_t* words = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n_streams * nc * 4);
+  if (!work || !words) return PCC_E_NOMEM;
+  hipLaunchKernelGGL(k_rans_enc, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
+                     view_of(tables), d_sym, d_idx, idx_run, n, T, nc, work, cap_words, words);
+  PCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_rans_pack, dim3((unsigned)(nc + 1), n_streams), dim3(256), 0, st, (const uint32_t*)work, cap_words,
+                     (const uint32_t*)words, n, T, nc, d_out, cap_each, d_lens);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_rans_encode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, const int32_t* d_sym, const uint8_t* d_idx,
+                                   int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
+                                   int64_t* h_lens) {
+  PCC_REQUIRE(ctx && h_lens && n_streams >= 1 && n_streams <= 64, PCC_E_ARG, "pcc_rans_encode_dev: bad argument");
+  long long* d_lens = nullptr;
+  PCC_HIP(hipMalloc((void**)&d_lens, 64 * 8));
   int rc = PCC_OK;
-  // first with room for one word per symbol and a half on top (escapes are rare), then with the worst case
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const int64_t cap_words = 2 * kLanes + (attempt == 0 ? kLanes * T * 3 / 2 + 64 : kLanes * T * 11);
-    const size_t work_bytes = (size_t)n_streams * nc * cap_words * 4;
-    PCC_TRY(pcc_arena_reserve(ctx, work_bytes + pcc_align((size_t)n_streams * nc * 4) + pcc_align((size_t)n_streams * 8) + 1024));
-    uint32_t* work = (uint32_t*)pcc_arena_alloc(ctx, work_bytes);
-    uint32_t* words = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n_streams * nc * 4);
-    long long* lens = (long long*)pcc_arena_alloc(ctx, (size_t)n_streams * 8);
-    if (!work || !words || !lens) return PCC_E_NOMEM;
-    hipLaunchKernelGGL(k_rans_enc, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
-                       view_of(tables), d_sym, d_idx, idx_run, n, T, nc, work, cap_words, words);
-    PCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_rans_pack, dim3((unsigned)(nc + 1), n_streams), dim3(256), 0, st, (const uint32_t*)work, cap_words,
-                       (const uint32_t*)words, n, T, nc, d_out, cap_each, lens);
-    PCC_CHECK_LAUNCH();
-    long long* h = (long long*)ctx->pinned;
-    PCC_REQUIRE((size_t)n_streams * 8 <= ctx->pinned_cap, PCC_E_ARG, "pcc_rans_encode_dev: too many streams");
-    PCC_HIP(hipMemcpyAsync(h, lens, (size_t)n_streams * 8, hipMemcpyDeviceToHost, st));
-    PCC_HIP(hipStreamSynchronize(st));
+    rc = pcc_rans_encode_dev_async(ctx, tables, d_sym, d_idx, idx_run, n, n_streams, d_out, cap_each, d_lens, attempt);
+    if (rc != PCC_OK) break;
+    long long h[64];
+    if (hipMemcpyAsync(h, d_lens, (size_t)n_streams * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      rc = PCC_E_HIP;
+      pcc_set_error("pcc_rans_encode_dev: read-back of the stream lengths failed");
+      break;
+    }
     rc = PCC_OK;
     for (int s = 0; s < n_streams; ++s) {
       h_lens[s] = h[s];
       if (h[s] < 0) rc = PCC_E_NOMEM;
     }
-    if (rc == PCC_OK) return PCC_OK;
+    if (rc == PCC_OK) break;
+    pcc_set_error("pcc_rans_encode_dev: a stream does not fit %lld bytes", (long long)cap_each);
   }
-  pcc_set_error("pcc_rans_encode_dev: a stream does not fit %lld bytes", (long long)cap_each);
+  (void)hipFree(d_lens);
   return rc;
 }
 

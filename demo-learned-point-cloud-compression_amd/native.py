@@ -55,7 +55,7 @@ def pack_checkpoint(tensors):
 class NativeCodec:
     """one codec = weights in HBM + stream + device pool: one per in-flight call"""
 
-    def __init__(self, tensors, device=0):
+    def __init__(self, tensors, device=0, container_version=0):
         if not torch.cuda.is_available():
             raise RuntimeError("demo-learned-point-cloud-compression_amd needs a HIP device (no CPU fallback)")
         self.lib = _abi.lib()
@@ -67,6 +67,9 @@ class NativeCodec:
             raise PccError(-1, "pcc_codec_create", self.lib.pcc_last_error().decode(errors="replace"))
         from .runtime import Runtime
         self.rt = Runtime.adopt(self.lib.pcc_codec_ctx(self.handle), self.stream, self.device)
+        if container_version:
+            check(self.lib.pcc_codec_set_container_version(self.handle, int(container_version)),
+                  "pcc_codec_set_container_version")
 
     def close(self):
         if getattr(self, "handle", None):

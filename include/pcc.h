@@ -340,6 +340,12 @@ int pcc_gaussian_quant16(pcc_ctx* ctx, const float* d_y, const float* d_params,
                          int64_t n, int c, const float* d_scale, int q,
                          const float* d_table, int n_tab, int16_t* d_sym,
                          uint8_t* d_idx, int32_t* d_flag);
+/* the same with int32 symbols and uint8 indexes, the element types the GPU
+ * coder reads (pcc_rans_encode_dev): nothing overflows, nothing crosses PCIe */
+int pcc_gaussian_quant_dev(pcc_ctx* ctx, const float* d_y, const float* d_params,
+                           int64_t n, int c, const float* d_scale, int q,
+                           const float* d_table, int n_tab, int32_t* d_sym,
+                           uint8_t* d_idx);
 int pcc_gaussian_indexes8(pcc_ctx* ctx, const float* d_params, int64_t n, int c,
                           const float* d_scale, const float* d_table, int n_tab,
                           uint8_t* d_idx);
@@ -508,7 +514,19 @@ typedef struct pcc_cloud_info {
 
 pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device, void* stream);
 void pcc_codec_destroy(pcc_codec* codec);
-pcc_ctx* pcc_codec_ctx(pcc_codec* codec); /* the codec's ctx (stream, profiler) */
+pcc_ctx* pcc_codec_ctx(pcc_codec* codec);
+/* Container version the encoder entry points of this codec write (default 0).
+ *   PCC_CONTAINER_V0  the reference's layout, byte for byte (make_bitstream_batched,
+ *                     codec_pipeline.py:464-517): y and z strings are single rANS
+ *                     streams, coded on the host (CompressAI's format)
+ *   PCC_CONTAINER_V1  the same fields, the top byte of the first word (num_frames,
+ *                     at most 65535) set to 1, and the y / z strings in the GPU
+ *                     coder's wave-interleaved form (pcc_rans_encode_dev): no serial
+ *                     host coder on the path.  The reference's decoder cannot read
+ *                     it; pcc_decode_gop reads both versions. */
+#define PCC_CONTAINER_V0 0
+#define PCC_CONTAINER_V1 1
+int pcc_codec_set_container_version(pcc_codec* codec, int version); /* the codec's ctx (stream, profiler) */
 
 /* d_coords int32 [n,4] rows (b,x,y,z), b in [0,n_frames); d_feats float32 [n,4]
  * = (1,r,g,b) (codec_pipeline.py:258); h_q [n_q,2] = (q_g,q_a) per quality

@@ -335,8 +335,10 @@ class Oracle:
         return keys, self.linear(h, w, b), offs
 
     # ------------------------------------------------------------ pipeline
-    def compress(self, frames, settings):
-        """frames: list of {"points": int[N,3], "colors": float[N,3]} -> ({1..Q: bytes}, debug dict)"""
+    def compress(self, frames, settings, version=0):
+        """frames: list of {"points": int[N,3], "colors": float[N,3]} -> ({1..Q: bytes}, debug dict).
+        version 0: the reference's container (single rANS streams); 1: this build's flagged extension — the same
+        fields, top byte of the first word 1, y / z strings in the interleaved form of the GPU coder"""
         pts, cols = [], []
         for f in frames:
             if "points" not in f:
@@ -362,8 +364,11 @@ class Oracle:
         zperm = self.canonical_perm(zcoords)
         zsym, zhat_sorted = self.factorized_quant(z[zperm])
         cz = zsym.shape[0]
-        z_string = self.rans_encode(zsym, np.repeat(np.arange(cz, dtype=np.int32), zsym.shape[1]),
-                                    "entropy_bottleneck")
+        if version == 1:
+            z_string = self.rans_interleaved_encode(zsym, None, "entropy_bottleneck", idx_run=max(zsym.shape[1], 1))
+        else:
+            z_string = self.rans_encode(zsym, np.repeat(np.arange(cz, dtype=np.int32), zsym.shape[1]),
+                                        "entropy_bottleneck")
         zk2, zhat = self.sparse_tensor(zcoords[zperm], zhat_sorted)
         pkeys, params = self.h_s(zk2, zhat)
         rows = self.lookup(pkeys, self.morton_keys(ycoords_sorted))
@@ -372,18 +377,21 @@ class Oracle:
         sym, idx = self.gaussian_quant(y_sorted, prm, scale)
         out = {}
         for qi, q in enumerate(settings):
-            y_string = self.rans_encode(sym[qi], idx[qi], "gaussian_conditional")
+            if version == 1:
+                y_string = self.rans_interleaved_encode(sym[qi], idx[qi], "gaussian_conditional")
+            else:
+                y_string = self.rans_encode(sym[qi], idx[qi], "gaussian_conditional")
             out[qi + 1] = self.make_bitstream(y_string, z_string, y_sorted.shape[0], zsym.shape[1], points_streams,
-                                              k, q)
+                                              k, q, version)
         dbg = {"ykeys": ykeys, "y": y, "k": k, "zkeys": zkeys, "z": z, "params_keys": pkeys, "params": params,
                "sym": sym, "idx": idx, "zsym": zsym, "points_streams": points_streams, "z_string": z_string,
                "scale": scale, "num_points": coords.shape[0]}
         return out, dbg
 
     @staticmethod
-    def make_bitstream(y_string, z_string, n_y, n_z, points_streams, ks, q):
-        """container writer, codec_pipeline.py:464-517 (big-endian fields)"""
-        parts = [struct.pack(">idd", len(points_streams), float(q[0]), float(q[1])),
+    def make_bitstream(y_string, z_string, n_y, n_z, points_streams, ks, q, version=0):
+        """container writer, codec_pipeline.py:464-517 (big-endian fields); version in the top byte of the first word"""
+        parts = [struct.pack(">idd", len(points_streams) | (version << 24), float(q[0]), float(q[1])),
                  struct.pack(">iiii", n_y, n_z, len(y_string), len(z_string)), y_string, z_string]
         for i, p in enumerate(points_streams):
             parts.append(struct.pack(">iiii", len(p), int(ks[0][i]), int(ks[1][i]), int(ks[2][i])))
@@ -395,6 +403,7 @@ class Oracle:
         """container reader, codec_parallel.py:173-216"""
         pos = 0
         nf, qg, qa = struct.unpack_from(">idd", data, pos); pos += 20
+        nf &= 0x00FFFFFF                      # the top byte is the container version (container_version())
         n_y, n_z, ly, lz = struct.unpack_from(">iiii", data, pos); pos += 16
         y_string = data[pos:pos + ly]; pos += ly
         z_string = data[pos:pos + lz]; pos += lz
@@ -405,7 +414,13 @@ class Oracle:
             streams.append(data[pos:pos + lp]); pos += lp
         return y_string, z_string, n_y, n_z, streams, ks, [qg, qa]
 
+    @staticmethod
+    def container_version(data):
+        return (struct.unpack_from(">I", data, 0)[0] >> 24) & 0xFF
+
     def decompress(self, data):
+        version = self.container_version(data)
+        assert version in (0, 1)
         y_string, z_string, n_y, n_z, streams, ks, q = self.read_bitstream(data)
         n_batch = len(streams)
         pts = [self.octree_decode(s) * 8 for s in streams]
@@ -418,7 +433,10 @@ class Oracle:
         zcoords_sorted = zcoords[self.canonical_perm(zcoords)]
         assert zcoords_sorted.shape[0] == n_z
         cz = self.t["entropy_bottleneck.medians"].shape[0]
-        zsym = self.rans_decode(z_string, np.repeat(np.arange(cz, dtype=np.int32), n_z), "entropy_bottleneck")
+        if version == 1:
+            zsym = self.rans_interleaved_decode(z_string, None, cz * n_z, "entropy_bottleneck", idx_run=max(n_z, 1))
+        else:
+            zsym = self.rans_decode(z_string, np.repeat(np.arange(cz, dtype=np.int32), n_z), "entropy_bottleneck")
         zhat_sorted = self.factorized_dequant(zsym.reshape(cz, n_z))
         zk2, zhat = self.sparse_tensor(zcoords_sorted, zhat_sorted)
         pkeys, params = self.h_s(zk2, zhat)
@@ -428,7 +446,10 @@ class Oracle:
         prm = np.where(rows[:, None] >= 0, params[np.maximum(rows, 0)], np.float32(0)).astype(np.float32)
         scale = (self.scale_nn([q]) + self.eps).astype(np.float32)
         idx = self.gaussian_indexes(prm, scale[0])
-        sym = self.rans_decode(y_string, idx, "gaussian_conditional")
+        if version == 1:
+            sym = self.rans_interleaved_decode(y_string, idx, idx.size, "gaussian_conditional")
+        else:
+            sym = self.rans_decode(y_string, idx, "gaussian_conditional")
         yhat_sorted = self.gaussian_dequant(sym.reshape(idx.shape), prm, scale[0])
         yk2, yhat = self.sparse_tensor(ycoords_sorted, yhat_sorted)
         xkeys, rgb, offs = self.g_s(yk2, yhat, ks, n_batch)

@@ -121,3 +121,82 @@ def test_malformed_streams_are_refused(rt, oracle, coders):
         except runtime.PccError as e:
             assert e.code == -5
     assert np.array_equal(gc.decode(rt, good, n, d_idx, 1).cpu().numpy(), sym)
+
+
+# ---------------------------------------------------------------------------------- whole containers, version 1
+SETTINGS = [[1.0, 0.0], [0.0, 1.0], [1, 1]]
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(x["points"], y["points"]) and np.array_equal(x["colors"], y["colors"])
+                                    for x, y in zip(a, b))
+
+
+@pytest.fixture(scope="module")
+def pipes():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    p = pkg()
+    return (p.CompressionPipeline(SETTINGS, slots=1), p.CompressionPipeline(SETTINGS, slots=1, container_version=1),
+            p.DecompressionPipeline(slots=1))
+
+
+def test_version1_containers_equal_oracle_and_decode_like_version0(pipes, oracle, wl):
+    """the flagged container: same fields, y / z strings from the GPU coder.  Bytes equal the oracle's version-1
+    containers; the decoder reads both versions and reconstructs the same frames from either (same symbols)"""
+    enc0, enc1, dec = pipes
+    frames = [wl.sphere_shell(40, 14.7, seed=3, offset=(-60, 11, -25)), wl.room(90_000, seed=2, extent=(128, 128, 64)),
+              wl.sphere_shell(24, 9.1, seed=5)]
+    out0, _ = enc0.compress(wl.gop([dict(f) for f in frames]))
+    out1, side1 = enc1.compress(wl.gop([dict(f) for f in frames]))
+    ref1, _ = oracle.compress([dict(f) for f in frames], SETTINGS, version=1)
+    for q in (1, 2, 3):
+        assert out1[q] == ref1[q], f"version-1 container {q} differs from the oracle"
+        assert out1[q][0] == 1 and out0[q][0] == 0                      # the flag: top byte of the first word
+        assert out1[q][1:20] == out0[q][1:20]                           # frame count, q_g, q_a unchanged
+        assert struct.unpack_from(">ii", out1[q], 20) == struct.unpack_from(">ii", out0[q], 20)   # N_y, N_z
+        rec1, _ = dec.decompress(out1[q])
+        rec0, _ = dec.decompress(out0[q])
+        assert _same(rec1, rec0)
+        assert _same(rec1, oracle.decompress(ref1[q]))
+    assert len(side1["gop_info"]["bpp"]) == 4
+    # the rate price of 64 states per chunk
+    assert len(out0[3]) < len(out1[3]) < 1.12 * len(out0[3]) + 2048
+
+
+def test_version1_full_size_bench_frame_equals_oracle(pipes, oracle, wl):
+    enc0, enc1, dec = pipes
+    frame = wl.room(1_000_000, seed=0)
+    out1, _ = enc1.compress(wl.gop([dict(frame)]))
+    ref1, _ = oracle.compress([dict(frame)], SETTINGS, version=1)
+    assert all(out1[q] == ref1[q] for q in (1, 2, 3))
+    rec1, _ = dec.decompress(out1[3])
+    assert _same(rec1, oracle.decompress(ref1[3]))
+    out0, _ = enc0.compress(wl.gop([dict(frame)]))
+    assert _same(rec1, dec.decompress(out0[3])[0])
+    assert len(out1[3]) < 1.08 * len(out0[3])
+
+
+def test_version1_corrupted_containers_never_fault(pipes, wl):
+    enc0, enc1, dec = pipes
+    native = pkg("native")
+    out1, _ = enc1.compress(wl.gop([wl.sphere_shell(32, 11.2, seed=8), wl.sphere_shell(20, 7.5, seed=4)]))
+    clean = out1[3]
+    n_ref = sum(f["points"].shape[0] for f in dec.decompress(clean)[0])
+    rng = np.random.default_rng(77)
+    outcomes = {"ok": 0, "error": 0}
+    for _ in range(60):
+        b = bytearray(clean)
+        pos = int(rng.integers(0, len(b)))
+        b[pos] ^= int(rng.integers(1, 256))
+        try:
+            rec, _ = dec.decompress(bytes(b))
+            outcomes["ok"] += 1
+        except native.PccError as e:
+            assert e.code < 0
+            outcomes["error"] += 1
+    assert outcomes["ok"] + outcomes["error"] == 60 and outcomes["error"] > 0
+    assert sum(f["points"].shape[0] for f in dec.decompress(clean)[0]) == n_ref
+    # an unknown version is refused
+    with pytest.raises(native.PccError):
+        dec.decompress(bytes([2]) + clean[1:])
