@@ -136,9 +136,12 @@ def main():
     dec = pkg.DecompressionPipeline(device=local, slots=1, output="numpy")
     dec_dev = pkg.DecompressionPipeline(device=local, slots=1, output="device")
 
-    def step(host=True):
+    enc_v1 = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, container_version=1)
+
+    def step(host=True, enc=enc):
         """one pass of the operator contract.  host=True: numpy frames in, numpy frames out (the contract of the
-        reference's operators); host=False: inputs resident in HBM, reconstruction left in HBM."""
+        reference's operators); host=False: inputs resident in HBM, reconstruction left in HBM.  enc: the pipeline
+        that writes the reference's container (default) or the flagged version-1 container (GPU-coded strings)."""
         src = frames if host else d_frames
         d = dec if host else dec_dev
         if world == 1:
@@ -183,12 +186,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(host):
+    def timed(host, enc=enc):
         fence()
         t_start = time.perf_counter()
         e_ms, d_ms, last = [], [], None
         for _ in range(args.steps):
-            last = step(host)
+            last = step(host, enc)
             e_ms.append(1e3 * (last[1]["timestamps"]["codec_end"] - last[1]["timestamps"]["codec_start"]))
             d_ms.append(1e3 * (last[3]["timestamps"]["codec_end"] - last[3]["timestamps"]["codec_start"]))
         fence()
@@ -211,6 +214,41 @@ def main():
     table, _ = prof_table(rts, args.steps)
     # secondary: the same K steps with the frame resident in HBM and the reconstruction left there (no events)
     elapsed_hbm, enc_ms_hbm, dec_ms_hbm, _ = timed(host=False)
+    # the flagged container (version 1): y / z strings coded by the GPU's interleaved rANS in both directions, no
+    # serial host coder on the path.  One profiled step for the coder kernels' own figures, then K timed steps.
+    gpu_rans = None
+    if world == 1:
+        step(True, enc_v1)
+        rts1 = enc_v1.runtimes + dec.runtimes
+        for r in rts1:
+            r.prof_enable(True, reserve=400)
+        out1, side1, rec1, dside1, _ = step(True, enc_v1)
+        torch.cuda.synchronize()
+        table1, _ = prof_table(rts1, 1)
+        elapsed_v1, enc_ms_v1, dec_ms_v1, (out1, side1, rec1, dside1, _) = timed(host=True, enc=enc_v1)
+        same = all(np.array_equal(a["points"], b["points"]) and np.array_equal(a["colors"], b["colors"])
+                   for a, b in zip(rec1, rec))
+        assert same, "version-1 container decodes to a different reconstruction"
+        gpu_rans = {"value": args.steps / elapsed_v1, "ms_per_step": 1e3 * elapsed_v1 / args.steps,
+                    "encode_ms": enc_ms_v1, "decode_ms": dec_ms_v1, "bpp": [float(b) for b in side1["gop_info"]["bpp"]],
+                    "reconstruction_equals_version0": bool(same), "kernels": {}}
+        for (op, dims), (cnt, tot) in table1:
+            if op in ("rans_encode_dev", "rans_decode_dev"):
+                n_sym, n_str, t_steps, n_chunks = dims
+                if n_sym < 100000:
+                    continue                      # the z stream: a single small launch
+                stream = (len(out1[q_dec]) if op == "rans_decode_dev" else sum(len(out1[q]) for q in range(1, q_dec + 1)))
+                nbytes = 5 * n_sym * n_str + stream     # int32 symbol + uint8 index per symbol, + the stream(s)
+                ms = tot / cnt
+                gpu_rans["kernels"][op] = {
+                    "symbols": int(n_sym * n_str), "chunks": int(n_chunks * n_str), "steps_per_chunk": int(t_steps),
+                    "avg_ms": ms, "algorithmic_bytes": int(nbytes),
+                    "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+                    "note": "one wave per chunk of 64 x steps symbols, steps coded one after the other: the launch "
+                            "lasts as long as ONE chunk (latency of a dependent 64-bit state update and a binary search "
+                            "in LDS per step), far from the HBM roof by construction; what it buys is the removal of the "
+                            "serial host coder and of the symbols' PCIe round trip"}
     table = [kv for kv in table if layer_all and kv[0] == (dom_op, dom_dims)]
     if rank == 0:
         log("per-op device time of the last warm-up step (HIP events around every C-ABI call):")
@@ -390,13 +428,17 @@ def main():
                        "points_per_step_per_gpu": n_pts, "frames_per_step_per_gpu": len(frames),
                        "qualities": len(SETTINGS), "decoded_quality": q_dec, "sharding": sharding,
                        "value_basis": "operator contract: host numpy frames in, host numpy frames out (PCIe legs inside "
-                                      "the timed region); value_hbm_resident = frame already in HBM, reconstruction "
-                                      "left in HBM"},
+                                      "the timed region), the reference's container (version 0: y / z strings single "
+                                      "rANS streams coded on the host); value_hbm_resident = frame already in HBM, "
+                                      "reconstruction left in HBM; value_gpu_rans = operator contract with the flagged "
+                                      "version-1 container (strings coded by the GPU's interleaved rANS)"},
             "encode_ms": enc_ms, "decode_ms": dec_ms,
             "value_hbm_resident": frames_total / elapsed_hbm,
             "ms_per_step_hbm_resident": 1e3 * elapsed_hbm / args.steps,
             "encode_ms_hbm_resident": enc_ms_hbm, "decode_ms_hbm_resident": dec_ms_hbm,
             "bpp": [float(b) for b in side["gop_info"]["bpp"]],
+            "value_gpu_rans": gpu_rans["value"] if gpu_rans else None,
+            "gpu_rans": gpu_rans,
             "d1_psnr": quality["hip"]["d1_psnr"] if quality else None,
             "y_psnr": quality["hip"]["y_psnr"] if quality else None,
             "d1_psnr_oracle": quality["oracle"]["d1_psnr"] if quality and "oracle" in quality else None,

@@ -44,10 +44,11 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 struct pcc_rans_dev {
   uint16_t* d_cdf = nullptr;   // all rows back to back; an entry of 65536 (end of a row) is stored as 0
   int32_t* d_row = nullptr;    // [3 n_cdf]: entry offset, length, symbol offset of every row
+  uint16_t* d_lut = nullptr;   // [n_cdf][65]: lut[r][b] = largest s with cdf[s] <= b << 10 (decoder: search window)
   int n_cdf = 0;
   int64_t entries = 0;
   int device = 0;
-  size_t lds_bytes() const { return ((size_t)entries * 2 + 15) / 16 * 16 + (size_t)n_cdf * 12; }
+  size_t lds_bytes() const { return ((size_t)entries * 2 + 15) / 16 * 16 + (size_t)n_cdf * 12 + (size_t)n_cdf * 65 * 2; }
 };
 
 extern "C" pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
@@ -56,7 +57,7 @@ extern "C" pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitc
     pcc_set_error("pcc_rans_dev_create: bad argument");
     return nullptr;
   }
-  std::vector<uint16_t> flat;
+  std::vector<uint16_t> flat, lut;
   std::vector<int32_t> row((size_t)3 * n_cdf);
   for (int r = 0; r < n_cdf; ++r) {
     const int len = h_sizes[r];
@@ -71,6 +72,13 @@ extern "C" pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitc
     row[3 * r + 1] = len;
     row[3 * r + 2] = h_offsets[r];
     for (int j = 0; j < len; ++j) flat.push_back((uint16_t)(c[j] & 0xFFFF));
+    // 64 buckets of 1024 cumulative counts: the symbol of bucket b's first count; entry 64 closes the last window
+    int sidx = 0;
+    for (int b = 0; b < 64; ++b) {
+      while (sidx + 1 < len - 1 && c[sidx + 1] <= (b << 10)) ++sidx;
+      lut.push_back((uint16_t)sidx);
+    }
+    lut.push_back((uint16_t)(len - 2));
   }
   pcc_rans_dev* t = new (std::nothrow) pcc_rans_dev();
   if (!t) return nullptr;
@@ -83,11 +91,14 @@ extern "C" pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitc
   }
   (void)hipGetDevice(&t->device);
   if (hipMalloc((void**)&t->d_cdf, flat.size() * 2) != hipSuccess || hipMalloc((void**)&t->d_row, row.size() * 4) != hipSuccess ||
+      hipMalloc((void**)&t->d_lut, lut.size() * 2) != hipSuccess ||
       hipMemcpy(t->d_cdf, flat.data(), flat.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(t->d_row, row.data(), row.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(t->d_row, row.data(), row.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(t->d_lut, lut.data(), lut.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
     pcc_set_error("pcc_rans_dev_create: upload failed");
     if (t->d_cdf) (void)hipFree(t->d_cdf);
     if (t->d_row) (void)hipFree(t->d_row);
+    if (t->d_lut) (void)hipFree(t->d_lut);
     delete t;
     return nullptr;
   }
@@ -98,12 +109,17 @@ extern "C" void pcc_rans_dev_destroy(pcc_rans_dev* t) {
   if (!t) return;
   (void)hipFree(t->d_cdf);
   (void)hipFree(t->d_row);
+  (void)hipFree(t->d_lut);
   delete t;
 }
 
-// steps per chunk for an array of n symbols: whole arrays of up to 32768 symbols are one chunk, larger ones are cut
-// into chunks of 64 x 512 (every chunk costs 512 B of final states: 5 % of a 2-bit-per-symbol stream at 512 steps)
-static inline int64_t steps_for(int64_t n) { return n > 32768 ? 512 : std::max<int64_t>((n + kLanes - 1) / kLanes, 1); }
+// steps per chunk for an array of n symbols.  A launch lasts as long as ONE chunk (its steps are sequential), and every
+// chunk costs 512 B of final states: whole arrays of up to 32768 symbols are one chunk; up to 262144 symbols (the z
+// string of a large GOP, the y string of a small one) chunks of 64 x 128; above, chunks of 64 x 512 (5 % of a 2-bit-per-
+// symbol stream)
+static inline int64_t steps_for(int64_t n) {
+  return n > 262144 ? 512 : n > 32768 ? 128 : std::max<int64_t>((n + kLanes - 1) / kLanes, 1);
+}
 static inline int64_t chunks_for(int64_t n, int64_t T) { return std::max<int64_t>((n + kLanes * T - 1) / (kLanes * T), 1); }
 
 extern "C" int64_t pcc_rans_dev_bound(int64_t n) {
@@ -117,14 +133,22 @@ extern "C" int64_t pcc_rans_dev_bound(int64_t n) {
 struct RansView {
   const uint16_t* cdf;
   const int32_t* row;
+  const uint16_t* lut;
   int n_cdf;
   int64_t entries;
 };
 
-// LDS image: uint16 cdf[entries] (padded to 16 B) | int32 row[3 n_cdf]
-__device__ __forceinline__ void stage_tables(const RansView& v, uint16_t* s_cdf, int32_t* s_row) {
-  for (int64_t i = threadIdx.x; i < v.entries; i += blockDim.x) s_cdf[i] = v.cdf[i];
+// LDS image: uint16 cdf[entries] (padded to 16 B) | int32 row[3 n_cdf] | uint16 lut[65 n_cdf] (decoder only)
+__device__ __forceinline__ void stage_tables(const RansView& v, uint16_t* s_cdf, int32_t* s_row, uint16_t* s_lut) {
+  // 16-B pieces of the CDF image, then the small tables
+  const int64_t n16 = (v.entries * 2 + 15) / 16;
+  const uint4* src = reinterpret_cast<const uint4*>(v.cdf);
+  uint4* dst = reinterpret_cast<uint4*>(s_cdf);
+  for (int64_t i = threadIdx.x; i < n16 - 1; i += blockDim.x) dst[i] = src[i];
+  for (int64_t i = (n16 - 1) * 8 + threadIdx.x; i < v.entries; i += blockDim.x) s_cdf[i] = v.cdf[i];
   for (int i = threadIdx.x; i < 3 * v.n_cdf; i += blockDim.x) s_row[i] = v.row[i];
+  if (s_lut)
+    for (int i = threadIdx.x; i < 65 * v.n_cdf; i += blockDim.x) s_lut[i] = v.lut[i];
   __syncthreads();
 }
 
@@ -132,7 +156,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long bal) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
 
-static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_row, t->n_cdf, t->entries}; }
+static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_row, t->d_lut, t->n_cdf, t->entries}; }
 
 // ---- encoder -----------------------------------------------------------------------------------------------------
 // One wave per chunk.  work: per stream and chunk a private buffer of cap_words; the chunk ends at the buffer's end.
@@ -144,7 +168,7 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   uint16_t* s_cdf = reinterpret_cast<uint16_t*>(s_raw);
   int32_t* s_row = reinterpret_cast<int32_t*>(s_raw + ((size_t)tv.entries * 2 + 15) / 16 * 16);
-  stage_tables(tv, s_cdf, s_row);
+  stage_tables(tv, s_cdf, s_row, nullptr);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * kChunksPerWg + wave;
   const int64_t s = blockIdx.y;
@@ -157,17 +181,32 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
   uint64_t x = kL;
   const int64_t base = c * kLanes * T;
 
+  // symbol and table index of the step after this one are requested before this step's arithmetic
+  auto fetch = [&](int64_t t, int32_t& sv, int& rv) {
+    const int64_t i = base + t * kLanes + lane;
+    sv = 0;
+    rv = 0;
+    if (t >= 0 && i < n) {
+      sv = ssym[i];
+      rv = sidx ? (int)sidx[i] : (int)(i / idx_run);
+    }
+  };
+  int32_t sv_n;
+  int rv_n;
+  fetch(T - 1, sv_n, rv_n);
   for (int64_t t = T - 1; t >= 0; --t) {
     const int64_t i = base + t * kLanes + lane;
     const bool act = i < n;
+    const int32_t sv = sv_n;
+    const int r = rv_n;
+    fetch(t - 1, sv_n, rv_n);
     int32_t start = 0, freq = 1, nb = 0;
     uint32_t raw = 0;
     bool esc = false;
     if (act) {
-      const int r = sidx ? (int)sidx[i] : (int)(i / idx_run);
       const int off = s_row[3 * r], len = s_row[3 * r + 1];
       const int32_t max_value = len - 2;
-      int32_t v = ssym[i] - s_row[3 * r + 2];
+      int32_t v = sv - s_row[3 * r + 2];
       if (v < 0) {
         raw = (uint32_t)(-2 * (int64_t)v - 1);
         v = max_value;
@@ -217,7 +256,16 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
         }
       }
       if (need) x >>= 32;
-      if (act) x = ((x / (uint32_t)freq) << 16) + (x % (uint32_t)freq) + (uint32_t)start;
+      if (act) {
+        // x / freq, x % freq with x < 2^47 freq: the quotient from one double division (exact to within one, the 53-bit
+        // mantissa holds any quotient below 2^47), corrected by the remainder — instead of the 64-bit division routine
+        const uint64_t f = (uint32_t)freq;
+        uint64_t qd = (uint64_t)((double)x / (double)f);
+        int64_t rem = (int64_t)(x - qd * f);
+        if (rem < 0) { --qd; rem += (int64_t)f; }
+        else if (rem >= (int64_t)f) { ++qd; rem -= (int64_t)f; }
+        x = (qd << 16) + (uint64_t)rem + (uint32_t)start;
+      }
     }
   }
   if (!overflow) {
@@ -289,7 +337,8 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   uint16_t* s_cdf = reinterpret_cast<uint16_t*>(s_raw);
   int32_t* s_row = reinterpret_cast<int32_t*>(s_raw + ((size_t)tv.entries * 2 + 15) / 16 * 16);
-  stage_tables(tv, s_cdf, s_row);
+  uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_row + 3 * tv.n_cdf);
+  stage_tables(tv, s_cdf, s_row, s_lut);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * kChunksPerWg + wave;
   if (c >= n_chunks) return;
@@ -308,32 +357,47 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   int64_t ptr = 2 * kLanes;
   const int64_t base = c * kLanes * T;
 
+  // The next 64 words of the chunk are requested as soon as the read position is known (one coalesced load per step),
+  // so a lane that renormalises takes its word from a register of another lane (ds_bpermute) instead of waiting for a
+  // load that depends on the state it has just computed.
+  auto window = [&](int64_t at) -> uint32_t { return at + lane < (int64_t)cw ? p[at + lane] : 0u; };
+  uint32_t win = window(ptr);
   auto refill = [&](bool need) {
     const unsigned long long bal = __ballot(need);
     const int cnt = __popcll(bal);
     if (cnt) {
+      const uint32_t w = (uint32_t)__shfl((int)win, lane_rank(bal), 64);
       if (ptr + cnt > (int64_t)cw) {
         bad |= 1;
         if (need) x = kL;   // keep the arithmetic defined; the status word reports the stream
       } else {
-        if (need) x = (x << 32) | p[ptr + lane_rank(bal)];
+        if (need) x = (x << 32) | w;
         ptr += cnt;
       }
+      win = window(ptr);
     }
   };
+  auto fetch_idx = [&](int64_t t) -> int {
+    const int64_t i = base + t * kLanes + lane;
+    if (t >= T || i >= n) return 0;
+    return idx ? (int)idx[i] : (int)(i / idx_run);
+  };
+  int r_n = fetch_idx(0);
 
   for (int64_t t = 0; t < T; ++t) {
     const int64_t i = base + t * kLanes + lane;
     const bool act = i < n;
+    const int r = r_n;
+    r_n = fetch_idx(t + 1);
     int32_t value = 0, max_value = 0, off_sym = 0;
     bool esc = false;
     if (act) {
-      const int r = idx ? (int)idx[i] : (int)(i / idx_run);
       const int off = s_row[3 * r], len = s_row[3 * r + 1];
       off_sym = s_row[3 * r + 2];
       max_value = len - 2;
       const uint32_t cum = (uint32_t)(x & 0xFFFFu);
-      int lo = 0, hi = len - 2;   // largest s with cdf[s] <= cum (cdf[0] = 0)
+      // largest s with cdf[s] <= cum, searched inside the window its 1024-count bucket gives
+      int lo = s_lut[65 * r + (cum >> 10)], hi = s_lut[65 * r + (cum >> 10) + 1];
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if ((uint32_t)s_cdf[off + mid] <= cum) lo = mid;

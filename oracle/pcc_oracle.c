@@ -414,11 +414,12 @@ ORC_API int orc_rans_decode(const uint8_t* in, int64_t len, const int32_t* idx, 
  *   payload = 64 x (state lo, state hi) | block(step 0, round 0) | block(0, 1) | .. | block(1, 0) | ..
  * Round 0 of a step codes the bins of all lanes, round r >= 1 the r-th bypass symbol of the lanes whose symbol
  * escaped (1 = nibble count, 2 + j = nibble j); a block holds the words the decoder reads after that round, in
- * ascending lane order.  T = 512 for arrays of more than 32768 symbols, else ceil(n / 64) (one chunk), at least 1.
+ * ascending lane order.  T = 512 for arrays of more than 262144 symbols, 128 for more than 32768, else ceil(n / 64)
+ * (one chunk), at least 1.
  * idx == NULL: table of symbol i = i / idx_run. */
 #define IL_LANES 64
 #define IL_MAGIC 0x31494350u
-static int64_t il_steps(int64_t n) { int64_t t = (n + IL_LANES - 1) / IL_LANES; if (n > 32768) return 512; return t < 1 ? 1 : t; }
+static int64_t il_steps(int64_t n) { int64_t t = (n + IL_LANES - 1) / IL_LANES; if (n > 262144) return 512; if (n > 32768) return 128; return t < 1 ? 1 : t; }
 
 typedef struct { uint32_t start, freq, raw; int nb, esc, act; } il_sym;
 
