@@ -68,14 +68,18 @@ class DecompressionPipeline:
             with rt:
                 y_strings, z_strings, y_shapes, z_shapes, points_streams, ks, q, t_1 = \
                     self.read_bitstream_batched(compressed_data)
+                version = self.container_version(compressed_data)
                 # the z string needs nothing from the GPU: decode it on the helper thread while the
-                # geometry is decoded and the z coordinates are re-derived on the device
+                # geometry is decoded and the z coordinates are re-derived on the device (version 1: the
+                # GPU coder decodes it in its place in the stream)
                 eb = self.decompression_model.entropy_model.entropy_bottleneck
-                z_sym = self._pool.submit(eb.decode_host, z_strings, int(z_shapes))
+                z_sym = self._pool.submit(eb.decode_host, z_strings, int(z_shapes)) if version == 0 else None
                 y_points, t_2 = self.geometry_decompression_step(points_streams)
-                z_hats, t_3 = self.factorized_model_step_batched(z_strings, z_shapes, y_points, z_sym=z_sym)
+                z_hats, t_3 = self.factorized_model_step_batched(z_strings, z_shapes, y_points, z_sym=z_sym,
+                                                                 version=version)
                 gaussian_params, t_4 = self.hyper_synthesis_step(z_hats)
-                y_hat, t_5 = self.gaussian_model_step_batched(y_strings, y_shapes, y_points, q, gaussian_params)
+                y_hat, t_5 = self.gaussian_model_step_batched(y_strings, y_shapes, y_points, q, gaussian_params,
+                                                              version=version)
                 reconstructed_pointcloud, t_6 = self.hyper_synthesis(y_hat, ks)
                 final_data, t_7 = self.pack_batches(reconstructed_pointcloud, len(points_streams))
         finally:
@@ -113,6 +117,14 @@ class DecompressionPipeline:
         return batch, sideinfo
 
     # ------------------------------------------------------------------ stages
+    @staticmethod
+    def container_version(compressed_data):
+        """top byte of the first word: 0 = the reference's container, 1 = y / z strings in the GPU coder's form"""
+        version = memoryview(compressed_data)[0] if len(compressed_data) else 0
+        if version not in (0, 1):
+            raise _rt.PccError(-5, "read_bitstream_batched", f"container version {version}")
+        return int(version)
+
     def read_bitstream_batched(self, compressed_data):
         """Step 1: parse the container (codec_parallel.py:173-216)"""
         t0 = time.time()
@@ -137,6 +149,7 @@ class DecompressionPipeline:
             return b
 
         num_frames, q_g, q_a = take(">idd")
+        num_frames &= 0x00FFFFFF                  # the top byte is the container version
         q = [q_g, q_a]
         y_shapes, z_shapes, y_len, z_len = take(">iiii")
         y_strings = [take_bytes(y_len)]
@@ -157,7 +170,7 @@ class DecompressionPipeline:
         y_points = utils.stack_tensors(y_points)
         return y_points, time.time() - t0
 
-    def factorized_model_step_batched(self, z_strings, z_shapes, y_points, z_sym=None):
+    def factorized_model_step_batched(self, z_strings, z_shapes, y_points, z_sym=None, version=0):
         """Step 3: re-derive the z coordinates from the y coordinates with two
         stride-2 maps, decode z (codec_parallel.py:291-318)"""
         t0 = time.time()
@@ -178,7 +191,7 @@ class DecompressionPipeline:
                                f"container says N_z={int(z_shapes)}, coordinates give {z_points.shape[0]}")
         eb = self.decompression_model.entropy_model.entropy_bottleneck
         z_hat_rows = eb.decompress_rows(rt, z_strings, int(z_shapes),
-                                        sym=z_sym.result() if z_sym is not None else None)
+                                        sym=z_sym.result() if z_sym is not None else None, version=version)
         z_hat = utils.sparse_from_rows(z_view, z_hat_rows)   # coordinates z_points, stride 32
         return z_hat, time.time() - t0
 
@@ -190,7 +203,7 @@ class DecompressionPipeline:
             gaussian_params.rt.sync()
         return gaussian_params, time.time() - t0
 
-    def gaussian_model_step_batched(self, y_strings, y_shapes, y_points, q, gaussian_params):
+    def gaussian_model_step_batched(self, y_strings, y_shapes, y_points, q, gaussian_params, version=0):
         """Step 5: decode y and de-quantise with offsets (codec_parallel.py:382-419)"""
         t0 = time.time()
         rt = _rt.current()
@@ -212,7 +225,7 @@ class DecompressionPipeline:
         scale_dev = rt.to_device(np.ascontiguousarray(scale, dtype=np.float32))
         a, b = em.offsets_ab
         y_hat_rows = em.gaussian_conditional.decompress_rows(rt, y_strings[0], gaussian_params_feats, scale_dev,
-                                                             a, b)
+                                                             a, b, version=version)
         y_hat = utils.sparse_from_rows(y_view, y_hat_rows)   # coordinates y_points, stride 8
         y_hat.cs.set_batches(n_frames)
         rt.y_latent = None

@@ -143,7 +143,7 @@ class CompressionPipeline:
                 t_7s = []
                 for i, q in enumerate(self.settings):
                     byte_array, t_7 = self.make_bitstream_batched(y_strings[i], z_strings, y_shapes, z_shapes,
-                                                                  points_streams, k, q)
+                                                                  points_streams, k, q, self.container_version)
                     compressed_data[i + 1] = byte_array
                     t_7s.append(t_7)
                 num_points = pointclouds.C.shape[0]
@@ -257,7 +257,7 @@ class CompressionPipeline:
         z_points = zs.C
         z_shapes = [int(zs.F.shape[0])]
         eb = self.compression_model.entropy_model.entropy_bottleneck
-        z_strings, zhat_rows = eb.compress_rows(rt, zs.F, defer=defer)
+        z_strings, zhat_rows = eb.compress_rows(rt, zs.F, defer=defer, version=self.container_version)
         z_hat = utils.sparse_from_rows(zs, zhat_rows)      # same coordinates as z, stride 32
         return z_hat, z_strings, z_shapes, z_points, time.time() - t0
 
@@ -276,7 +276,7 @@ class CompressionPipeline:
         ys = getattr(y, "_sorted", None) or utils.sort_tensor(y)
         gaussian_param = gaussian_params.features_at_coordinates(ys.C)
         gc = self.compression_model.entropy_model.gaussian_conditional
-        y_strings = gc.compress_rows(rt, ys.F, gaussian_param, self._scale_dev)
+        y_strings = gc.compress_rows(rt, ys.F, gaussian_param, self._scale_dev, version=self.container_version)
         shapes = [int(ys.F.shape[0])]
         return y_strings, shapes, time.time() - t0
 
@@ -298,15 +298,16 @@ class CompressionPipeline:
         point_bitstreams = finish()
         return point_bitstreams, time.time() - t0
 
-    def make_bitstream_batched(self, y_string, z_string, y_shape, z_shape, points_streams, ks, q):
+    def make_bitstream_batched(self, y_string, z_string, y_shape, z_shape, points_streams, ks, q, version=0):
         """Step 7: byte container, field for field the reference writer
         (codec_pipeline.py:464-517; `bitstream` writes MSB first = big-endian):
         int32 num_frames | f64 q_g | f64 q_a | int32 N_y | int32 N_z | int32 len_y
         | int32 len_z | y_string | z_string | F x (int32 len_pts | int32 k1 |
-        int32 k2 | int32 k3 | pts)."""
+        int32 k2 | int32 k3 | pts).  version (0 = the reference's container) goes into the top byte of the
+        first word; version 1 = y / z strings in the GPU coder's interleaved form."""
         t0 = time.time()
         num_frames = len(points_streams)
-        parts = [struct.pack(">idd", num_frames, float(q[0]), float(q[1])),
+        parts = [struct.pack(">idd", num_frames | (int(version) << 24), float(q[0]), float(q[1])),
                  struct.pack(">iiii", int(y_shape[0]), int(z_shape[0]), len(y_string), len(z_string[0])),
                  y_string, z_string[0]]
         for i in range(num_frames):

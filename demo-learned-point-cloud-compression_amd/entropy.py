@@ -22,6 +22,14 @@ class _Coder:
         self.cdf = np.ascontiguousarray(cdf, dtype=np.int32)
         self.length = np.ascontiguousarray(length, dtype=np.int32)
         self.offset = np.ascontiguousarray(offset, dtype=np.int32)
+        self._dev = None
+
+    @property
+    def dev(self):
+        """the same tables in HBM, for the GPU coder of container version 1 (made on first use)"""
+        if self._dev is None:
+            self._dev = _rt.RansDev(self.cdf, self.length, self.offset)
+        return self._dev
 
     def encode(self, sym, idx):
         """sym, idx: int32 numpy [S, n] -> list of S byte strings"""
@@ -49,12 +57,16 @@ class EntropyBottleneck:
         return np.repeat(np.arange(self.channels, dtype=np.int32), n)
 
     # fused form used by the pipeline: z rows [N,C] in coding order
-    def compress_rows(self, rt, z_rows, defer=False):
+    def compress_rows(self, rt, z_rows, defer=False, version=0):
         """returns (strings, z_hat rows).  With defer=True `strings` is a zero-argument function
         doing the host rANS (to be called once the stream has passed this point): z_hat is formed
-        on the device and does not depend on the byte string."""
+        on the device and does not depend on the byte string.  version=1: the string in the GPU coder's
+        interleaved form (container version 1)."""
         sym, zhat = rt.factorized_quant(z_rows, self.medians)
         n = z_rows.shape[0]
+        if version == 1:
+            strings = self.coder.dev.encode(rt, sym.reshape(1, -1), None, max(n, 1))
+            return ((lambda: strings) if defer else strings), zhat
         sym_h = rt.to_host_async(sym, "z_sym")
 
         def finish():
@@ -69,7 +81,10 @@ class EntropyBottleneck:
         """host half of decompress: rANS decode of the z string -> int32 [C*n] (no GPU involved)"""
         return self.coder.decode(strings[0], self._indexes(n))
 
-    def decompress_rows(self, rt, strings, n, sym=None):
+    def decompress_rows(self, rt, strings, n, sym=None, version=0):
+        if version == 1:
+            sym_d = self.coder.dev.decode(rt, strings[0], self.channels * n, None, max(n, 1)).view(self.channels, n)
+            return rt.factorized_dequant(sym_d, self.medians)
         if sym is None:
             sym = self.decode_host(strings, n)
         sym_d = rt.to_device(sym.reshape(self.channels, n), torch.int32)
@@ -129,9 +144,12 @@ class GaussianConditional:
         return rt.to_device(out.reshape(idx_h.shape).astype(np.float32))
 
     # fused forms used by the pipeline ------------------------------------
-    def compress_rows(self, rt, y_rows, params_rows, scale_q):
-        """y_rows [N,C], params_rows [N,2C], scale_q device [Q,C] -> Q byte strings"""
+    def compress_rows(self, rt, y_rows, params_rows, scale_q, version=0):
+        """y_rows [N,C], params_rows [N,2C], scale_q device [Q,C] -> Q byte strings (version=1: interleaved form)"""
         q = scale_q.shape[0]
+        if version == 1:
+            sym, idx = rt.gaussian_quant_dev(y_rows, params_rows, scale_q, self.scale_table)
+            return self.coder.dev.encode(rt, sym.reshape(q, -1), idx.reshape(q, -1))
         sym, idx, flag = rt.gaussian_quant16(y_rows, params_rows, scale_q, self.scale_table)
         sym_h = rt.to_host_async(sym, "y_sym")
         idx_h = rt.to_host_async(idx, "y_idx")
@@ -142,10 +160,13 @@ class GaussianConditional:
             sym_h, idx_h = sym.cpu().numpy(), idx.cpu().numpy()
         return self.coder.encode(sym_h.reshape(q, -1), idx_h.reshape(q, -1))
 
-    def decompress_rows(self, rt, string, params_rows, scale_1, off_a, off_b):
+    def decompress_rows(self, rt, string, params_rows, scale_1, off_a, off_b, version=0):
         """one quality: returns y_hat rows [N,C] (offset de-quantisation applied)"""
         n, c = params_rows.shape[0], params_rows.shape[1] // 2
         idx = rt.gaussian_indexes8(params_rows, scale_1, self.scale_table)
+        if version == 1:
+            sym_d = self.coder.dev.decode(rt, string, c * n, idx.reshape(-1), 1).view(c, n)
+            return rt.gaussian_dequant(sym_d, params_rows, scale_1, float(self.scale_bound), float(off_a), float(off_b))
         idx_h = rt.to_host_async(idx, "y_idx")
         rt.sync()
         stage = rt.pinned("y_dec", 4 * c * n)[:4 * c * n].view(torch.int32)

@@ -449,6 +449,16 @@ class Runtime:
               "pcc_gaussian_quant16")
         return sym, idx, flag
 
+    def gaussian_quant_dev(self, y, params, scale, table):
+        """int32 symbols, uint8 indexes — the element types the GPU coder reads (pcc_gaussian_quant_dev)"""
+        n, c = y.shape
+        q = scale.shape[0]
+        sym = self.empty((q, c, n), torch.int32)
+        idx = self.empty((q, c, n), torch.uint8)
+        check(self.lib.pcc_gaussian_quant_dev(self.ctx, _ptr(y), _ptr(params), n, c, _ptr(scale), q, _ptr(table),
+                                              table.shape[0], _ptr(sym), _ptr(idx)), "pcc_gaussian_quant_dev")
+        return sym, idx
+
     def gaussian_indexes8(self, params, scale, table):
         n, c = params.shape[0], params.shape[1] // 2
         idx = self.empty((c, n), torch.uint8)

@@ -201,3 +201,19 @@ def test_version1_corrupted_containers_never_fault(pipes, wl):
     # an unknown version is refused
     with pytest.raises(native.PccError):
         dec.decompress(bytes([2]) + clean[1:])
+
+
+def test_version1_through_the_op_by_op_engine(pipes, wl):
+    """engine="ops" (the reference's stage methods one by one in Python) writes and reads version 1 as well: the
+    same bytes as the native engine, the same frames from either container"""
+    p = pkg()
+    enc0, enc1, dec = pipes
+    enc_o = p.CompressionPipeline(SETTINGS, slots=1, engine="ops", container_version=1)
+    dec_o = p.DecompressionPipeline(slots=1, engine="ops")
+    frames = [wl.sphere_shell(32, 11.2, seed=8, offset=(30, -70, 5)), wl.sphere_shell(24, 9.1, seed=2)]
+    out_o, _ = enc_o.compress(wl.gop([dict(f) for f in frames]))
+    out_n, _ = enc1.compress(wl.gop([dict(f) for f in frames]))
+    assert all(out_o[q] == out_n[q] for q in (1, 2, 3))
+    assert _same(dec_o.decompress(out_o[2])[0], dec.decompress(out_n[2])[0])
+    out0, _ = enc0.compress(wl.gop([dict(f) for f in frames]))
+    assert _same(dec_o.decompress(out0[2])[0], dec.decompress(out_n[2])[0])
