@@ -115,6 +115,100 @@ extern "C" int pcc_down_coords_known(pcc_ctx* ctx, const uint64_t* d_keys, int64
   return down_coords_impl(ctx, d_keys, n, child_shift, d_pkeys, d_nbr8, n_cap, d_parent_of, m, &got);
 }
 
+// ---- the same with the parent count known in advance: two launches, no flag / offset arrays.
+// Tile = 2048 keys (256 threads x 8).  Pass 1 counts the parents that START in each tile (a key starts a parent when
+// its predecessor has another parent key); pass 2 recomputes those flags, adds up the counts of the tiles in front of
+// its own (at most 2048 tiles: 4M keys), scans, and emits parent keys, the kernel-2 rule book and parent_of directly.
+#define DC_THREADS 256
+#define DC_ITEMS 8
+#define DC_TILE (DC_THREADS * DC_ITEMS)
+
+__device__ __forceinline__ uint32_t dc_wave_incl(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t dc_block_excl(uint32_t v, uint32_t* total, uint32_t* lds /*[4]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = dc_wave_incl(v);
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < DC_THREADS / 64; ++w) {
+    const uint32_t sv = lds[w];
+    if (w < wave) base += sv;
+    tot += sv;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(DC_THREADS) void k_parent_tile_counts(const uint64_t* __restrict__ keys, int64_t n, int pshift,
+                                                                   uint32_t* __restrict__ sums) {
+  __shared__ uint32_t lds[4];
+  const int64_t base = (int64_t)blockIdx.x * DC_TILE + (int64_t)threadIdx.x * DC_ITEMS;
+  uint32_t c = 0;
+  uint64_t prev = base > 0 && base - 1 < n ? keys[base - 1] >> pshift : 0ull;
+#pragma unroll
+  for (int j = 0; j < DC_ITEMS; ++j) {
+    const int64_t i = base + j;
+    if (i < n) {
+      const uint64_t pk = keys[i] >> pshift;
+      c += (i == 0 || pk != prev) ? 1u : 0u;
+      prev = pk;
+    }
+  }
+  uint32_t tot;
+  dc_block_excl(c, &tot, lds);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(DC_THREADS) void k_parent_scan_emit(const uint64_t* __restrict__ keys, int64_t n, int cshift,
+                                                                 const uint32_t* __restrict__ sums,
+                                                                 uint64_t* __restrict__ pkeys, int32_t* __restrict__ nbr8,
+                                                                 int64_t m, int32_t* __restrict__ parent_of /*nullable*/) {
+  __shared__ uint32_t lds[4];
+  const int pshift = cshift + 3;
+  const int64_t base = (int64_t)blockIdx.x * DC_TILE + (int64_t)threadIdx.x * DC_ITEMS;
+  uint32_t part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += DC_THREADS) part += sums[i];
+  uint32_t tile_off;
+  dc_block_excl(part, &tile_off, lds);
+  uint64_t kv[DC_ITEMS];
+  uint32_t f[DC_ITEMS];
+  uint32_t c = 0;
+  uint64_t prev = base > 0 && base - 1 < n ? keys[base - 1] >> pshift : 0ull;
+#pragma unroll
+  for (int j = 0; j < DC_ITEMS; ++j) {
+    const int64_t i = base + j;
+    kv[j] = i < n ? keys[i] : 0ull;
+    const uint64_t pk = kv[j] >> pshift;
+    f[j] = (i < n && (i == 0 || pk != prev)) ? 1u : 0u;
+    prev = pk;
+    c += f[j];
+  }
+  uint32_t tot;
+  uint32_t ex = dc_block_excl(c, &tot, lds) + tile_off;   // parents started in front of this thread's first key
+#pragma unroll
+  for (int j = 0; j < DC_ITEMS; ++j) {
+    const int64_t i = base + j;
+    ex += f[j];
+    if (i >= n) continue;
+    const int64_t p = (int64_t)ex - 1;
+    if (p >= m) continue;   // a caller-supplied m smaller than the real parent count: never write past it
+    const int o = (int)((kv[j] >> cshift) & 7ull);
+    if (f[j]) pkeys[p] = (kv[j] >> pshift) << pshift;
+    nbr8[(int64_t)o * m + p] = (int32_t)i;
+    if (parent_of) parent_of[i] = (int32_t)p;
+  }
+}
+
 static int down_coords_impl(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift, uint64_t* d_pkeys,
                             int32_t* d_nbr8, int64_t n_cap, int32_t* d_parent_of, int64_t m_known,
                             int64_t* h_n_out) {
@@ -126,6 +220,21 @@ static int down_coords_impl(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int
   PCC_REQUIRE(d_keys && d_pkeys && d_nbr8 && n_cap >= n, PCC_E_ARG, "pcc_down_coords: bad buffers");
   PCC_REQUIRE(n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_down_coords: n too large");
   hipStream_t st = ctx->stream;
+  const int64_t tiles = (n + DC_TILE - 1) / DC_TILE;
+  if (m_known >= 0 && tiles <= DC_TILE) {
+    PCC_TRY(pcc_arena_reserve(ctx, pcc_align((size_t)tiles * 4) + 512));
+    uint32_t* sums = (uint32_t*)pcc_arena_alloc(ctx, (size_t)tiles * 4);
+    if (!sums) return PCC_E_NOMEM;
+    PccProfScope prof(ctx, "down_coords", n, child_shift, 0, 0);
+    PCC_HIP(hipMemsetAsync(d_nbr8, 0xFF, (size_t)8 * m_known * 4, st));   // -1: octants without a child
+    hipLaunchKernelGGL(k_parent_tile_counts, dim3((unsigned)tiles), dim3(DC_THREADS), 0, st, d_keys, n, child_shift + 3, sums);
+    PCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_parent_scan_emit, dim3((unsigned)tiles), dim3(DC_THREADS), 0, st, d_keys, n, child_shift,
+                       (const uint32_t*)sums, d_pkeys, d_nbr8, m_known, d_parent_of);
+    PCC_CHECK_LAUNCH();
+    *h_n_out = m_known;
+    return PCC_OK;
+  }
   PCC_TRY(pcc_arena_reserve(ctx, 2 * pcc_align((size_t)n * 4) + pcc_scan_scratch_bytes(n) + 512));
   uint32_t* flags = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
   uint32_t* excl = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);

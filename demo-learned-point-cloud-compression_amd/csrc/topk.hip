@@ -7,14 +7,16 @@
 // the order-preserving integer image of the logit (4 histogram passes), ties at
 // the threshold are resolved by row order (lower Morton key first); one prefix
 // scan over the "above" and "equal" flags ranks both and places the survivors
-// (stable compaction).  9 launches per call (was 20: every block now advances the
-// threshold state itself from the finished histograms instead of a one-block
-// update launch per pass): at the sizes of this path a call is launch-bound, not
+// (stable compaction).  7 launches per call (was 20, then 9: every block advances the
+// threshold state itself from the finished histograms instead of a one-block update
+// launch per pass, and the flags / scan / placement are two launches over per-frame
+// tiles instead of four): at the sizes of this path a call is launch-bound, not
 // bandwidth-bound.
 // No sort of the 2M candidates, no floating-point comparisons that could
 // differ between encoder, decoder and the CPU oracle.
 #include "common.h"
 #include <string.h>
+#include <algorithm>
 
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
@@ -147,6 +149,113 @@ __global__ __launch_bounds__(256) void k_topk_emit(const uint32_t* __restrict__ 
   }
 }
 
+// The same in two launches without flag / offset arrays, for frames of up to 4M candidates (2048 tiles of 2048):
+// k_topk_tile_counts counts, per frame and tile, the keys above and equal to the threshold; k_topk_place recomputes
+// them, adds up the counts of the frame's tiles in front of its own, scans its tile and writes the kept rows.
+#define TK_ITEMS 8
+#define TK_TILE (256 * TK_ITEMS)
+
+__device__ __forceinline__ uint2 tk_block_excl2(uint2 v, uint2* total, uint32_t* lds /*[8]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint2 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t a = __shfl_up(inc.x, d, 64), b = __shfl_up(inc.y, d, 64);
+    if (lane >= d) { inc.x += a; inc.y += b; }
+  }
+  if (lane == 63) { lds[2 * wave] = inc.x; lds[2 * wave + 1] = inc.y; }
+  __syncthreads();
+  uint2 base = make_uint2(0u, 0u), tot = make_uint2(0u, 0u);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t a = lds[2 * w], b = lds[2 * w + 1];
+    if (w < wave) { base.x += a; base.y += b; }
+    tot.x += a; tot.y += b;
+  }
+  __syncthreads();
+  *total = tot;
+  return make_uint2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+}
+
+// grid (tiles, F); sums [F][tiles][2]
+__global__ __launch_bounds__(256) void k_topk_tile_counts(const uint32_t* __restrict__ keys, const int64_t* __restrict__ offs,
+                                                          const TopkState* __restrict__ state0,
+                                                          const uint32_t* __restrict__ hist, int n_frames,
+                                                          uint32_t* __restrict__ sums) {
+  __shared__ uint32_t st_lds[8];
+  const int f = blockIdx.y;
+  const int64_t lo = offs[f], hi = offs[f + 1];
+  const int64_t base = lo + (int64_t)blockIdx.x * TK_TILE + (int64_t)threadIdx.x * TK_ITEMS;
+  const TopkState s = topk_state_after(state0[f], hist, n_frames, f, 4, st_lds);
+  uint2 c = make_uint2(0u, 0u);
+  if (s.mode == 2) {
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; ++j)
+      if (base + j < hi) {
+        const uint32_t k = keys[base + j];
+        c.x += k > s.prefix ? 1u : 0u;
+        c.y += k == s.prefix ? 1u : 0u;
+      }
+  } else if (s.mode == 1) {
+#pragma unroll
+    for (int j = 0; j < TK_ITEMS; ++j) c.x += base + j < hi ? 1u : 0u;
+  }
+  uint2 tot;
+  tk_block_excl2(c, &tot, st_lds);
+  if (threadIdx.x == 0) {
+    sums[((size_t)f * gridDim.x + blockIdx.x) * 2] = tot.x;
+    sums[((size_t)f * gridDim.x + blockIdx.x) * 2 + 1] = tot.y;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_topk_place(const uint32_t* __restrict__ keys, const int64_t* __restrict__ offs,
+                                                    const TopkState* __restrict__ state0,
+                                                    const uint32_t* __restrict__ hist, int n_frames,
+                                                    const uint32_t* __restrict__ sums, uint32_t* __restrict__ rows) {
+  __shared__ uint32_t st_lds[8];
+  const int f = blockIdx.y;
+  const int64_t lo = offs[f], hi = offs[f + 1];
+  if (lo + (int64_t)blockIdx.x * TK_TILE >= hi) return;   // block-uniform
+  const int64_t base = lo + (int64_t)blockIdx.x * TK_TILE + (int64_t)threadIdx.x * TK_ITEMS;
+  const TopkState s = topk_state_after(state0[f], hist, n_frames, f, 4, st_lds);
+  if (s.mode == 0) return;
+  uint2 part = make_uint2(0u, 0u);
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) {
+    part.x += sums[((size_t)f * gridDim.x + t) * 2];
+    part.y += sums[((size_t)f * gridDim.x + t) * 2 + 1];
+  }
+  uint2 tile_off;
+  tk_block_excl2(part, &tile_off, st_lds);
+  uint32_t gt[TK_ITEMS], eq[TK_ITEMS];
+  uint2 c = make_uint2(0u, 0u);
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; ++j) {
+    gt[j] = 0u;
+    eq[j] = 0u;
+    if (base + j < hi) {
+      if (s.mode == 1) gt[j] = 1u;
+      else {
+        const uint32_t k = keys[base + j];
+        gt[j] = k > s.prefix ? 1u : 0u;
+        eq[j] = k == s.prefix ? 1u : 0u;
+      }
+    }
+    c.x += gt[j];
+    c.y += eq[j];
+  }
+  uint2 tot;
+  uint2 ex = tk_block_excl2(c, &tot, st_lds);
+  ex.x += tile_off.x;
+  ex.y += tile_off.y;
+#pragma unroll
+  for (int j = 0; j < TK_ITEMS; ++j) {
+    const bool keep = gt[j] || (eq[j] && ex.y < s.k_rem);
+    if (keep) rows[s.keep_base + ex.x + min(ex.y, s.k_rem)] = (uint32_t)(base + j);
+    ex.x += gt[j];
+    ex.y += eq[j];
+  }
+}
+
 // per-frame parameters of a small GOP travel as kernel arguments: no pinned staging, hence no
 // stream synchronisation on their account
 #define TOPK_ARG_FRAMES 8
@@ -224,6 +333,21 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
     hipLaunchKernelGGL(k_topk_hist, grid2, dim3(256), 0, st, d_logits, keys, (const int64_t*)offs,
                        (const TopkState*)state, pass, hist, n_batch);
     PCC_CHECK_LAUNCH();
+  }
+  const unsigned tiles = std::max(1u, nblk(max_cnt, TK_TILE));
+  if (max_cnt <= (int64_t)TK_TILE * TK_TILE && (size_t)n_batch * tiles * 2 <= (size_t)n * 2) {
+    // two launches: counts per tile, then scan + placement (no flag / offset arrays)
+    uint32_t* sums = fl;   // [F][tiles][2], in the flag array of the four-launch form
+    const dim3 gridt(tiles, (unsigned)n_batch);
+    hipLaunchKernelGGL(k_topk_tile_counts, gridt, dim3(256), 0, st, (const uint32_t*)keys, (const int64_t*)offs,
+                       (const TopkState*)state, (const uint32_t*)hist, n_batch, sums);
+    PCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_topk_place, gridt, dim3(256), 0, st, (const uint32_t*)keys, (const int64_t*)offs,
+                       (const TopkState*)state, (const uint32_t*)hist, n_batch, (const uint32_t*)sums, d_keep_rows);
+    PCC_CHECK_LAUNCH();
+    if (h_n_keep) *h_n_keep = kept;
+    if (!by_arg) PCC_HIP(hipStreamSynchronize(st));
+    return PCC_OK;
   }
   hipLaunchKernelGGL(k_topk_flags, grid2, dim3(256), 0, st, (const uint32_t*)keys, (const int64_t*)offs,
                      (const TopkState*)state, (const uint32_t*)hist, n_batch, n, fl);

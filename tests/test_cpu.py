@@ -485,3 +485,47 @@ def test_d1_and_luma_psnr_known_answers():
     assert abs(c_ab) < 1e-30 and abs(c_ba - 0.125) < 1e-12 and abs(y - 9.0309) < 1e-4
     assert m.d1_psnr(a, a, 7)[0] == float("inf")
     assert m.peak_of(np.array([[-200, -150, -100], [311, 361, 155]])) == 511
+
+
+def _orc_interleaved(oracle, sym, idx, idx_run, cdf, sizes, offs):
+    import ctypes as C
+    sym = np.ascontiguousarray(sym, np.int32)
+    out = np.empty(48 * sym.shape[0] + 4096, np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)                                      # noqa: E731
+    oracle.lib.orc_rans_interleaved_encode.restype = C.c_int64
+    n = oracle.lib.orc_rans_interleaved_encode(p(sym), p(idx) if idx is not None else None, C.c_int64(idx_run),
+                                               C.c_int64(sym.shape[0]), p(cdf), C.c_int(cdf.shape[1]), p(sizes), p(offs),
+                                               p(out), C.c_int64(out.shape[0]))
+    assert n >= 0
+    return out[:n].tobytes()
+
+
+def test_interleaved_rans_known_answer_and_round_trip(oracle):
+    """the stream of container version 1 (csrc/rans_gpu.hip, restated in pcc_oracle.c), by hand for one symbol.
+    Table cdf = [0, 32768, 65536] (one regular bin, one escape bin), one symbol 0: one chunk of 64 x 1 steps, lane 0
+    codes the symbol, lanes 1..63 own nothing.  Lane 0: x = ((2^31 / 32768) << 16) + 0 = 2^32 (test_rans_known_answer),
+    no renormalisation word; the other states stay at L = 2^31.
+      header  'PCI1' | n = 1 | T = 1 | chunks = 1 | words[0] = 128 (the 64 states, two words each)
+      payload lane 0: (lo, hi) = (0, 1); lanes 1..63: (0x80000000, 0)"""
+    cdf = np.array([[0, 32768, 65536, 0]], dtype=np.int32)
+    sizes, offs = np.array([3], np.int32), np.array([0], np.int32)
+    got = _orc_interleaved(oracle, np.array([0], np.int32), np.zeros(1, np.uint8), 1, cdf, sizes, offs)
+    want = b"PCI1" + struct.pack("<IIII", 1, 1, 1, 128) + struct.pack("<II", 0, 1) + struct.pack("<II", 0x80000000, 0) * 63
+    assert got == want
+    # an escaped symbol in lane 1 adds bypass rounds but, from these states, still no word: sym = -3 -> the single-
+    # stream KAT's state 2^40 + 32849 (test_rans_bypass_escape_known_answers) appears as lane 1's final state
+    got2 = _orc_interleaved(oracle, np.array([0, -3], np.int32), np.zeros(2, np.uint8), 1, cdf, sizes, offs)
+    lanes = struct.unpack_from("<128I", got2, 20)
+    assert struct.unpack_from("<IIII", got2, 4) == (2, 1, 1, 128) and len(got2) == 20 + 512
+    assert (lanes[0], lanes[1]) == (0, 1) and (lanes[2], lanes[3]) == (32849, 256)
+    # round trips on the model's tables, table per symbol and table per channel run
+    rng = np.random.default_rng(4)
+    for which, n, run in (("gaussian_conditional", 70001, None), ("entropy_bottleneck", 32 * 500, 500)):
+        c, s, o = _tables(oracle, which)
+        idx = rng.integers(0, c.shape[0], n).astype(np.uint8) if run is None else None
+        sym = rng.integers(-40, 41, n).astype(np.int32)
+        sym[::997] = rng.integers(-10 ** 6, 10 ** 6, len(sym[::997]))
+        data = oracle.rans_interleaved_encode(sym, idx, which, idx_run=run or 1)
+        assert np.array_equal(oracle.rans_interleaved_decode(data, idx, n, which, idx_run=run or 1), sym)
+        with pytest.raises(ValueError):
+            oracle.rans_interleaved_decode(data[:-4], idx, n, which, idx_run=run or 1)
