@@ -136,7 +136,7 @@ def main():
     dec = pkg.DecompressionPipeline(device=local, slots=1, output="numpy")
     dec_dev = pkg.DecompressionPipeline(device=local, slots=1, output="device")
 
-    enc_v1 = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, container_version=1)
+    enc_v1 = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, container_version=1) if world == 1 else None
 
     def step(host=True, enc=enc):
         """one pass of the operator contract.  host=True: numpy frames in, numpy frames out (the contract of the
