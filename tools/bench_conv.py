@@ -67,6 +67,15 @@ def main():
                 # the form the native decoder runs: the candidates' rule book formed in-kernel from the parents' book
                 pn = pruned2.nbr27()
                 fns.append(("head_up", lambda: rt.sparse_conv_head_up(x, pn, w, b, True, hw, hb)))
+                # the same with the input rows cold: four input tensors (4 x 417 MB > the 256 MB Infinity Cache) in turn,
+                # as in the decoder, where the rows were written once by the up stage in front
+                xs = [x] + [torch.randn((cs.n, 32), generator=gw, device="cuda").contiguous() for _ in range(3)]
+                turn = [0]
+
+                def cold():
+                    turn[0] = (turn[0] + 1) % 4
+                    return rt.sparse_conv_head_up(xs[turn[0]], pn, w, b, True, hw, hb)
+                fns.append(("head_up_cold", cold))
             for label, fn in fns:
                 for _ in range(3):
                     fn()
