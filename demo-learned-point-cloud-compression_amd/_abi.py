@@ -44,6 +44,8 @@ PROTOTYPES = {
                              C.POINTER(C.c_double)]),
     "pcc_encode_gop_frames": (i32, [vp, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p), i32, pi64, i32,
                                     C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64, C.POINTER(C.c_double)]),
+    "pcc_encode_gop_host_frames": (i32, [vp, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p), i32, pi64, i32,
+                                         C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64, C.POINTER(C.c_double)]),
     "pcc_decode_gop": (i32, [vp, vp, i64, C.POINTER(PccCloudInfo), C.POINTER(C.c_double)]),
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
     "pcc_decode_fetch_packed": (i32, [vp, vp, vp]),

@@ -172,6 +172,20 @@ class CompressionPipeline:
         items = [it for it in frames if "points" in it.keys()]
         codec = self._slots.get()
         try:
+            host = [it for it in items if isinstance(it["points"], np.ndarray) and isinstance(it["colors"], np.ndarray)]
+            if (len(host) == len(items) and 1 <= len(items) <= codec.MAX_FRAMES
+                    and len({it["points"].dtype for it in items}) == 1 and len({it["colors"].dtype for it in items}) == 1
+                    and items[0]["points"].dtype in (np.int16, np.int32)
+                    and items[0]["colors"].dtype in (np.float32, np.float64)
+                    and all(it["points"].ndim == 2 and it["points"].shape[1:] == (3,)
+                            and it["colors"].shape == it["points"].shape for it in items)):
+                # the reference's case: numpy frames straight from the capturer.  The library uploads them itself,
+                # the colours underneath the key sort
+                pts = [np.ascontiguousarray(it["points"]) for it in items]
+                cols = [np.ascontiguousarray(it["colors"]) for it in items]
+                num_points = sum(int(p.shape[0]) for p in pts)
+                out, k, times = codec.encode_host_frames(pts, cols, self.settings)
+                return self._finish_native(data, compressed_data, out, times, num_points, t_start)
             with torch.cuda.stream(codec.stream):
                 pts = [_to_dev_as_is(it["points"], (torch.int16, torch.int32), torch.int32, self.device)
                        for it in items]
@@ -190,6 +204,10 @@ class CompressionPipeline:
                     out, k, times = codec.encode(coords.contiguous(), feats.contiguous(), len(items), self.settings)
         finally:
             self._slots.put(codec)
+        return self._finish_native(data, compressed_data, out, times, num_points, t_start)
+
+    @staticmethod
+    def _finish_native(data, compressed_data, out, times, num_points, t_start):
         for i, b in enumerate(out):
             compressed_data[i + 1] = b
         t_w = times.pop("bitstream_writing")

@@ -830,6 +830,11 @@ struct FrameTab {
   long long off[PCC_MAX_FRAMES_ARG + 1];  // row offsets of the frames in the concatenation
   int nf, pts_i16, cols_f64;
 };
+// the frames still in host memory (pcc_encode_gop_host_frames): uploaded inside encode_gop_impl, colours behind the sort
+struct HostFrames {
+  const void* const* pts;
+  const void* const* cols;
+};
 
 __device__ __forceinline__ int frame_of(const FrameTab& t, long long i) {
   int f = 0;
@@ -877,9 +882,9 @@ __global__ __launch_bounds__(256) void k_frames_feats(FrameTab t, const uint32_t
 
 static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n, int n_frames,
                            const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s,
-                           const FrameTab* frames = nullptr) {
+                           const FrameTab* frames_in = nullptr, const HostFrames* host = nullptr) {
   PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_encode_gop: null codec");
-  PCC_REQUIRE(n > 0 && (frames || (d_coords && d_feats)) && n_frames >= 1 && n_frames <= 65535 && h_q && n_q >= 1 &&
+  PCC_REQUIRE(n > 0 && (frames_in || (d_coords && d_feats)) && n_frames >= 1 && n_frames <= 65535 && h_q && n_q >= 1 &&
                   n_q <= 64 && h_out,
               PCC_E_ARG, "pcc_encode_gop: bad argument (n=%lld frames=%d q=%d)", (long long)n, n_frames, n_q);
   pcc_ctx* ctx = cd->ctx;
@@ -901,6 +906,27 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     CODEC_ALLOC(perm, uint32_t, n);
     CODEC_ALLOC(f, float, 4 * n);
     PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
+    FrameTab ftab;
+    const FrameTab* frames = frames_in;
+    if (host) {
+      // the frame arrays are host memory: points first (6 B per point), keys + sort are queued behind them, and the
+      // colours (24 B per point as float64) cross PCIe while the GPU sorts
+      ftab = *frames_in;
+      const size_t pb = ftab.pts_i16 ? 6 : 12, cb = ftab.cols_f64 ? 24 : 12;
+      char* dp = (char*)cd->pool.alloc((size_t)n * pb + 256 * (size_t)ftab.nf);
+      char* dc = (char*)cd->pool.alloc((size_t)n * cb + 256 * (size_t)ftab.nf);
+      if (!dp || !dc) return PCC_E_NOMEM;
+      size_t po = 0, co = 0;
+      for (int f = 0; f < ftab.nf; ++f) {
+        const size_t nf = (size_t)(ftab.off[f + 1] - ftab.off[f]);
+        ftab.pts[f] = dp + po;
+        ftab.cols[f] = dc + co;
+        if (nf) PCC_HIP(hipMemcpyAsync(dp + po, host->pts[f], nf * pb, hipMemcpyHostToDevice, st));
+        po += (nf * pb + 255) & ~(size_t)255;
+        co += (nf * cb + 255) & ~(size_t)255;
+      }
+      frames = &ftab;
+    }
     if (frames) {
       hipLaunchKernelGGL(k_frames_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *frames, n, keys, flag);
       PCC_CHECK_LAUNCH();
@@ -908,6 +934,13 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
     }
     PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
+    if (host) {  // the colours, while the sort runs (a pageable source blocks this thread, not the GPU)
+      const size_t cb = frames->cols_f64 ? 24 : 12;
+      for (int f = 0; f < frames->nf; ++f) {
+        const size_t nf = (size_t)(frames->off[f + 1] - frames->off[f]);
+        if (nf) PCC_HIP(hipMemcpyAsync(const_cast<void*>(frames->cols[f]), host->cols[f], nf * cb, hipMemcpyHostToDevice, st));
+      }
+    }
     PCC_TRY(cd->pin_flag.ensure(64));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
     // one read-back for the duplicate check and the sizes of the five pyramid levels above the input (g_a: strides
@@ -1778,6 +1811,36 @@ extern "C" int pcc_encode_gop_frames(pcc_codec* cd, const void* const* h_d_point
     return PCC_E_NOMEM;
   } catch (const std::exception& e) {
     pcc_set_error("pcc_encode_gop_frames: %s", e.what());
+    return PCC_E_ARG;
+  }
+}
+
+extern "C" int pcc_encode_gop_host_frames(pcc_codec* cd, const void* const* h_points, int points_i16,
+                                          const void* const* h_colors, int colors_f64, const int64_t* h_n, int n_frames,
+                                          const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s) {
+  PCC_REQUIRE(h_points && h_colors && h_n && n_frames >= 1, PCC_E_ARG, "pcc_encode_gop_host_frames: null frame table");
+  PCC_REQUIRE(n_frames <= PCC_MAX_FRAMES_ARG, PCC_E_ARG, "pcc_encode_gop_host_frames: %d frames, at most %d per call",
+              n_frames, PCC_MAX_FRAMES_ARG);
+  FrameTab t;
+  memset(&t, 0, sizeof(t));
+  t.nf = n_frames;
+  t.pts_i16 = points_i16 ? 1 : 0;
+  t.cols_f64 = colors_f64 ? 1 : 0;
+  for (int f = 0; f < n_frames; ++f) {
+    PCC_REQUIRE(h_n[f] >= 0 && (h_n[f] == 0 || (h_points[f] && h_colors[f])), PCC_E_ARG,
+                "pcc_encode_gop_host_frames: frame %d: n=%lld or null arrays", f, (long long)h_n[f]);
+    t.off[f + 1] = t.off[f] + h_n[f];
+  }
+  const int64_t n = t.off[n_frames];
+  PCC_REQUIRE(n < ((int64_t)1 << 32), PCC_E_ARG, "pcc_encode_gop_host_frames: %lld points", (long long)n);
+  const HostFrames host{h_points, h_colors};
+  try {
+    return encode_gop_impl(cd, nullptr, nullptr, n, n_frames, h_q, n_q, h_out, h_k, h_stage_s, &t, &host);
+  } catch (const std::bad_alloc&) {
+    pcc_set_error("pcc_encode_gop_host_frames: out of host memory");
+    return PCC_E_NOMEM;
+  } catch (const std::exception& e) {
+    pcc_set_error("pcc_encode_gop_host_frames: %s", e.what());
     return PCC_E_ARG;
   }
 }

@@ -130,6 +130,31 @@ class NativeCodec:
         ks = [[int(k[s * nf + f]) for f in range(nf)] for s in range(3)]
         return out, ks, dict(zip(ENC_STAGES, ts))
 
+    def encode_host_frames(self, points, colors, settings):
+        """the same on HOST arrays as compress(gop) receives them: numpy points [n_f,3] int16 or int32, colours [n_f,3]
+        float64 or float32, C-contiguous, one dtype per list.  The library uploads them and overlaps the colours' PCIe
+        leg with the key sort (pcc_encode_gop_host_frames)."""
+        nf, nq = len(points), len(settings)
+        assert 1 <= nf <= self.MAX_FRAMES and len(colors) == nf
+        pdt, cdt = points[0].dtype, colors[0].dtype
+        assert pdt in (np.int16, np.int32) and cdt in (np.float32, np.float64)
+        for p, c in zip(points, colors):
+            assert p.dtype == pdt and c.dtype == cdt and p.flags.c_contiguous and c.flags.c_contiguous
+            assert p.shape == c.shape and p.ndim == 2 and p.shape[1] == 3
+        pp = (C.c_void_p * nf)(*[p.ctypes.data for p in points])
+        cp = (C.c_void_p * nf)(*[c.ctypes.data for c in colors])
+        ns = (C.c_int64 * nf)(*[int(p.shape[0]) for p in points])
+        q = (C.c_double * (2 * nq))(*[float(v) for s in settings for v in s[:2]])
+        bufs = (_abi.PccBuf * nq)()
+        k = (C.c_int64 * (3 * nf))()
+        ts = (C.c_double * 7)()
+        check(self.lib.pcc_encode_gop_host_frames(self.handle, pp, 1 if pdt == np.int16 else 0, cp,
+                                                  1 if cdt == np.float64 else 0, ns, nf, q, nq, bufs, k, ts),
+              "pcc_encode_gop_host_frames")
+        out = [C.string_at(bufs[i].data, bufs[i].len) for i in range(nq)]
+        ks = [[int(k[s * nf + f]) for f in range(nf)] for s in range(3)]
+        return out, ks, dict(zip(ENC_STAGES, ts))
+
     # ------------------------------------------------------------------ decode
     def decode(self, data, packed_host=False):
         """container bytes -> (coords int32 [n,4] device, colors float32 [n,3] device, offsets, q, stage seconds).

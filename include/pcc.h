@@ -514,7 +514,8 @@ typedef struct pcc_cloud_info {
 
 pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device, void* stream);
 void pcc_codec_destroy(pcc_codec* codec);
-pcc_ctx* pcc_codec_ctx(pcc_codec* codec);
+pcc_ctx* pcc_codec_ctx(pcc_codec* codec); /* the codec's ctx (stream, profiler) */
+
 /* Container version the encoder entry points of this codec write (default 0).
  *   PCC_CONTAINER_V0  the reference's layout, byte for byte (make_bitstream_batched,
  *                     codec_pipeline.py:464-517): y and z strings are single rANS
@@ -526,7 +527,7 @@ pcc_ctx* pcc_codec_ctx(pcc_codec* codec);
  *                     it; pcc_decode_gop reads both versions. */
 #define PCC_CONTAINER_V0 0
 #define PCC_CONTAINER_V1 1
-int pcc_codec_set_container_version(pcc_codec* codec, int version); /* the codec's ctx (stream, profiler) */
+int pcc_codec_set_container_version(pcc_codec* codec, int version);
 
 /* d_coords int32 [n,4] rows (b,x,y,z), b in [0,n_frames); d_feats float32 [n,4]
  * = (1,r,g,b) (codec_pipeline.py:258); h_q [n_q,2] = (q_g,q_a) per quality
@@ -554,6 +555,16 @@ int pcc_encode_gop_frames(pcc_codec* codec, const void* const* h_d_points,
                           int colors_f64, const int64_t* h_n, int n_frames,
                           const double* h_q, int n_q, pcc_buf* h_out,
                           int64_t* h_k, double* h_stage_s);
+/* The same with the frame arrays still in HOST memory, as compress(gop) receives
+ * them from the capturer over ZeroMQ (codec_pipeline.py:243-262): h_points[f] /
+ * h_colors[f] are host arrays.  The library uploads them itself and overlaps the
+ * two PCIe legs with the start of the path: the points go up first, the Morton
+ * keys and their sort run while the (4x larger, float64) colours follow. */
+int pcc_encode_gop_host_frames(pcc_codec* codec, const void* const* h_points,
+                               int points_i16, const void* const* h_colors,
+                               int colors_f64, const int64_t* h_n, int n_frames,
+                               const double* h_q, int n_q, pcc_buf* h_out,
+                               int64_t* h_k, double* h_stage_s);
 /* h_stage_s (nullable) double[6] seconds = bitstream_reading,
  * geometry_decompression, factorized_model, hyper_synthesis, guassian_model,
  * synthesis_transform.  Truncated / inconsistent containers: PCC_E_STREAM. */
