@@ -1,5 +1,5 @@
 // Drives the whole-GOP C-ABI of include/pcc.h from a plain C++ program: no Python, no torch.
-//   cabi_main <ckpt.pccw> <coords.i32> <feats.f32> <n> <n_frames> <out_prefix>
+//   cabi_main <ckpt.pccw> <coords.i32> <feats.f32> <n> <n_frames> <out_prefix> [container_version]
 // Encodes the GOP at the three settings of shared/config.yaml:12-15, writes <out_prefix>.q{1,2,3}.bin, decodes
 // quality 3 again and writes <out_prefix>.xyz.i32 / <out_prefix>.rgb.f32 / <out_prefix>.offsets.i64.
 // tests/test_gpu_cabi.py compares all of it with the Python pipelines and the oracle.
@@ -35,7 +35,7 @@ static void spit(const std::string& path, const void* p, size_t n) {
 #define PCCOK(x) do { int rc_ = (x); if (rc_ != PCC_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, pcc_last_error()); return 4; } } while (0)
 
 int main(int argc, char** argv) {
-  if (argc != 7) { fprintf(stderr, "usage: cabi_main ckpt coords feats n n_frames out_prefix\n"); return 1; }
+  if (argc != 7 && argc != 8) { fprintf(stderr, "usage: cabi_main ckpt coords feats n n_frames out_prefix [version]\n"); return 1; }
   const std::vector<uint8_t> ckpt = slurp(argv[1]), coords = slurp(argv[2]), feats = slurp(argv[3]);
   const int64_t n = atoll(argv[4]);
   const int n_frames = atoi(argv[5]);
@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
 
   pcc_codec* codec = pcc_codec_create(ckpt.data(), ckpt.size(), 0, nullptr);
   if (!codec) { fprintf(stderr, "pcc_codec_create: %s\n", pcc_last_error()); return 4; }
+  if (argc == 8) PCCOK(pcc_codec_set_container_version(codec, atoi(argv[7])));   // 1: y / z strings coded on the GPU
   int32_t* d_coords = nullptr;
   float* d_feats = nullptr;
   HIPOK(hipMalloc((void**)&d_coords, coords.size()));

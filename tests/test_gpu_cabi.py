@@ -16,7 +16,8 @@ torch = pytest.importorskip("torch")
 SETTINGS = [[1.0, 0.0], [0.0, 1.0], [1, 1]]
 
 
-def test_c_program_drives_the_codec(tmp_path, wl, oracle):
+@pytest.mark.parametrize("version", [0, 1])
+def test_c_program_drives_the_codec(tmp_path, wl, oracle, version):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available on this box")
@@ -36,10 +37,11 @@ def test_c_program_drives_the_codec(tmp_path, wl, oracle):
     feats.tofile(tmp_path / "feats.f32")
     prefix = str(tmp_path / "out")
     res = subprocess.run([exe, str(tmp_path / "ckpt.pccw"), str(tmp_path / "coords.i32"), str(tmp_path / "feats.f32"),
-                          str(coords.shape[0]), str(len(frames)), prefix], capture_output=True, text=True, timeout=300)
+                          str(coords.shape[0]), str(len(frames)), prefix] + ([str(version)] if version else []),
+                         capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.startswith("ok ")
-    ref, _ = oracle.compress(frames, SETTINGS)
+    ref, _ = oracle.compress(frames, SETTINGS, version=version)
     for q in (1, 2, 3):
         assert open(f"{prefix}.q{q}.bin", "rb").read() == ref[q], f"container {q} differs from the oracle"
     k = np.fromfile(prefix + ".k.i64", np.int64).reshape(3, len(frames))
