@@ -355,8 +355,10 @@ extern "C" int pcc_inverse_rows(pcc_ctx* ctx, const uint32_t* d_rows, int64_t m,
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_inverse_rows: null ctx");
   if (n <= 0) return PCC_OK;
   PCC_REQUIRE(d_remap && (m == 0 || d_rows) && m <= n, PCC_E_ARG, "pcc_inverse_rows: bad buffers");
-  hipLaunchKernelGGL(k_fill_neg1, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_remap, n);
-  PCC_CHECK_LAUNCH();
+  if (m < n) {  // a full permutation (m == n; the caller's rows are distinct) writes every entry itself
+    hipLaunchKernelGGL(k_fill_neg1, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_remap, n);
+    PCC_CHECK_LAUNCH();
+  }
   if (m > 0) {
     hipLaunchKernelGGL(k_inverse_rows, dim3(nblk(m, 256)), dim3(256), 0, ctx->stream, d_rows, m, d_remap);
     PCC_CHECK_LAUNCH();

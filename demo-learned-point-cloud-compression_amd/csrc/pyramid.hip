@@ -149,9 +149,12 @@ __device__ __forceinline__ uint32_t dc_block_excl(uint32_t v, uint32_t* total, u
   return base + inc - v;
 }
 
+// (also presets the kernel-2 rule book, 8 m entries, to -1 = "octant without a child": the emit launch follows)
 __global__ __launch_bounds__(DC_THREADS) void k_parent_tile_counts(const uint64_t* __restrict__ keys, int64_t n, int pshift,
-                                                                   uint32_t* __restrict__ sums) {
+                                                                   uint32_t* __restrict__ sums, int32_t* __restrict__ nbr8,
+                                                                   int64_t nbr8_n) {
   __shared__ uint32_t lds[4];
+  for (int64_t i = (int64_t)blockIdx.x * DC_THREADS + threadIdx.x; i < nbr8_n; i += (int64_t)gridDim.x * DC_THREADS) nbr8[i] = -1;
   const int64_t base = (int64_t)blockIdx.x * DC_TILE + (int64_t)threadIdx.x * DC_ITEMS;
   uint32_t c = 0;
   uint64_t prev = base > 0 && base - 1 < n ? keys[base - 1] >> pshift : 0ull;
@@ -226,8 +229,8 @@ static int down_coords_impl(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int
     uint32_t* sums = (uint32_t*)pcc_arena_alloc(ctx, (size_t)tiles * 4);
     if (!sums) return PCC_E_NOMEM;
     PccProfScope prof(ctx, "down_coords", n, child_shift, 0, 0);
-    PCC_HIP(hipMemsetAsync(d_nbr8, 0xFF, (size_t)8 * m_known * 4, st));   // -1: octants without a child
-    hipLaunchKernelGGL(k_parent_tile_counts, dim3((unsigned)tiles), dim3(DC_THREADS), 0, st, d_keys, n, child_shift + 3, sums);
+    hipLaunchKernelGGL(k_parent_tile_counts, dim3((unsigned)tiles), dim3(DC_THREADS), 0, st, d_keys, n, child_shift + 3, sums,
+                       d_nbr8, 8 * m_known);
     PCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_parent_scan_emit, dim3((unsigned)tiles), dim3(DC_THREADS), 0, st, d_keys, n, child_shift,
                        (const uint32_t*)sums, d_pkeys, d_nbr8, m_known, d_parent_of);

@@ -172,7 +172,8 @@ int pcc_up_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
  *          there and d_remap maps rows of that level back to pruned rows (-1
  *          if dropped); pass both NULL when parent rows == rule-book rows.
  *  - down: children/parents linked by pcc_down_coords (d_parent_of, d_nbr8).
- *  - pcc_inverse_rows: remap[rows[j]] = j, -1 elsewhere (n entries). */
+ *  - pcc_inverse_rows: remap[rows[j]] = j, -1 elsewhere (n entries; rows distinct,
+ *    so with m == n every entry is written and nothing is preset). */
 int pcc_derive_map_up(pcc_ctx* ctx, const int32_t* d_nbr_parent,
                       int64_t parent_pitch, const uint32_t* d_parent_rows,
                       const int32_t* d_remap, int64_t n_parents, int32_t* d_nbr);
