@@ -29,10 +29,16 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 
 #define GC_WAVES 4
 
+#include "conv16.h"
+
 // The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound, and with one neighbour-index load and one gather
 // per offset in sequence every offset paid two dependent memory latencies.  All 27 neighbour indices of the tile are
-// fetched at once, and the rows and weights of offset k+1 are in flight while offset k is contracted.  The gathered
-// 32 x 4 tile goes through a wave-private LDS tile (pitch 5 floats: conflict-free) into the MFMA A operand.
+// fetched at once, and the rows of offset k+1 are in flight while offset k is contracted.  The gathered 32 x 4 tile
+// goes through a wave-private LDS tile (pitch 5 floats: conflict-free) into the MFMA B operand; the 13.8 KB of weights
+// sit in LDS (one load per workgroup; as two dword loads per offset and wave they were half of the kernel's loads); the
+// product is computed transposed (D[co][row]) so that a lane stores 16 B at a time: 105 -> 89 us.  Tried and slower:
+// 64-row windows without the LDS tile (registers), index loads split between the two half-waves (14 full-wave loads
+// + v_permlane32_swap instead of 27 half-wave ones: 103 us).
 __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
@@ -41,6 +47,9 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
   constexpr int COUT = 32;
   constexpr int PITCH = CIN + 1;
   __shared__ float a_lds[GC_WAVES][32 * PITCH];
+  __shared__ float w_lds[27 * CIN * COUT];   // 13.8 KB: one load per workgroup instead of two dword loads per offset and wave
+  for (int t = threadIdx.x; t < k_vol * CIN * COUT; t += GC_WAVES * 64) w_lds[t] = w[t];
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
   if (row0 >= n_out) return;  // wave-uniform
@@ -48,11 +57,8 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
   float* a = a_lds[wave];
 
   f32x16 acc[NT];
-  {
-    const float b = bias[i];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = b;
-  }
+  for (int r = 0; r < 16; ++r) acc[0][r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
 
   const bool row_ok = (row0 + i) < n_out;
   {
@@ -65,18 +71,12 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
       return v;
     };
     float4 gn = rows_of(nbs[0]);
-    float wn0 = w[(0 + h) * COUT + i], wn1 = w[(2 + h) * COUT + i];
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
       const float4 gc = gn;
-      const float wc0 = wn0, wc1 = wn1;
-      if (k + 1 < 27) {
-        gn = rows_of(nbs[k + 1]);  // -1 past k_vol: no load
-        const int kn = k + 1 < k_vol ? k + 1 : k_vol - 1;
-        wn0 = w[((int64_t)kn * CIN + 0 + h) * COUT + i];
-        wn1 = w[((int64_t)kn * CIN + 2 + h) * COUT + i];
-      }
+      if (k + 1 < 27) gn = rows_of(nbs[k + 1]);  // -1 past k_vol: no load
       if (k < k_vol && __ballot(nbs[k] >= 0) != 0ull) {  // uniform: somebody in this tile has offset k
+        const float wc0 = w_lds[(k * CIN + 0 + h) * COUT + i], wc1 = w_lds[(k * CIN + 2 + h) * COUT + i];
         if (lane < 32) {
           float* d = a + lane * PITCH;
           d[0] = gc.x; d[1] = gc.y; d[2] = gc.z; d[3] = gc.w;
@@ -84,28 +84,29 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i * PITCH + 0 + h], wc0, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i * PITCH + 2 + h], wc1, acc[0], 0, 0, 0);
+        // transposed product D[co][row] = W^T x X^T: a lane ends up with 16 channels of ONE row (16-B stores below)
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc0, a[i * PITCH + 0 + h], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc1, a[i * PITCH + 2 + h], acc[0], 0, 0, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
     }
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue: D layout col = lane & 31 = row slot, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = channel:
+  // lane (i, h) holds channels 8 j + 4 h + (0..3), j = 0..3, of row row0 + i: four 16-B stores
+  const int64_t g = row0 + i;
+  if (g < n_out) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int64_t g = row0 + row;
-    if (g < n_out) {
-      float v = acc[0][r];
-      if (relu) v = fmaxf(v, 0.0f);
-      out[g * COUT + i] = v;
+    for (int j = 0; j < 4; ++j) {
+      float4 v = make_float4(acc[0][4 * j], acc[0][4 * j + 1], acc[0][4 * j + 2], acc[0][4 * j + 3]);
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(out + g * COUT + 8 * j + 4 * h) = v;
     }
   }
 }
-
-#include "conv16.h"
 
 // scalar-fmaf reference path on the GPU (any cin/cout), same bits as the MFMA path
 __global__ __launch_bounds__(256) void k_gconv_scalar(
@@ -392,7 +393,7 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
       launch16<false, false, false, 32>(st, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
     else
       launch16<false, false, false, 64>(st, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
-  } else if (!force_scalar() && (uintptr_t)d_in % 16 == 0 && cin == 4 && cout == 32) {
+  } else if (!force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 && cout == 32) {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
     hipLaunchKernelGGL(k_gconv_first, dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
                        nbr_pitch, n_out, d_w, d_bias, relu, d_out);
