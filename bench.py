@@ -102,8 +102,15 @@ def main():
     backend = os.environ.get("PCC_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
+    # PCC_BENCH_TILED=1: the tiled (N > 1) workload and its RCCL exchange with a world of one rank — rehearses that
+    # leg on a one-GPU box; never the headline
+    tiled_mode = world > 1 or os.environ.get("PCC_BENCH_TILED") == "1"
     dist = None
-    if world > 1:
+    if tiled_mode:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -119,7 +126,7 @@ def main():
 
     # ---- workload.  N = 1: the C2 frame.  N > 1: two 500k-voxel octree blocks of the tiled scan per rank.
     t0 = time.time()
-    if world == 1:
+    if not tiled_mode:
         frames = [wl.room(args.points, seed=0)]
     else:
         # room `rank` of a fused scan of `world` C2 rooms side by side along x, cut into its two octree blocks
@@ -136,7 +143,7 @@ def main():
     dec = pkg.DecompressionPipeline(device=local, slots=1, output="numpy")
     dec_dev = pkg.DecompressionPipeline(device=local, slots=1, output="device")
 
-    enc_v1 = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, container_version=1) if world == 1 else None
+    enc_v1 = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, container_version=1) if not tiled_mode else None
 
     def step(host=True, enc=enc):
         """one pass of the operator contract.  host=True: numpy frames in, numpy frames out (the contract of the
@@ -144,7 +151,7 @@ def main():
         that writes the reference's container (default) or the flagged version-1 container (GPU-coded strings)."""
         src = frames if host else d_frames
         d = dec if host else dec_dev
-        if world == 1:
+        if not tiled_mode:
             out, side = enc.compress({"frames": [dict(f) for f in src], "timestamps": {}})
             rec, dside = d.decompress(out[q_dec])
             return out, side, rec, dside, out[q_dec]
@@ -174,7 +181,7 @@ def main():
             for r in rts:
                 r.prof_enable(True, reserve=400)
         out, side, rec, dside, decoded = step()
-    assert sum(int(r["points"].shape[0]) for r in rec) == n_pts or world > 1
+    assert sum(int(r["points"].shape[0]) for r in rec) == n_pts or tiled_mode
     torch.cuda.synchronize()
     table_all, sum_all = prof_table(rts, 1)
     layer_all = [(k, v) for k, v in table_all if k[0] in ("sparse_conv", "convT_gen")]
@@ -217,7 +224,7 @@ def main():
     # the flagged container (version 1): y / z strings coded by the GPU's interleaved rANS in both directions, no
     # serial host coder on the path.  One profiled step for the coder kernels' own figures, then K timed steps.
     gpu_rans = None
-    if world == 1:
+    if not tiled_mode:
         step(True, enc_v1)
         rts1 = enc_v1.runtimes + dec.runtimes
         for r in rts1:
@@ -340,7 +347,7 @@ def main():
     # the codec (3 pool threads, sender/encoder/encoder.py:50, receiver/decoder/decoder.py:47): host
     # entropy coding of one frame overlaps GPU work of another.  Not the reported `value`.
     inflight = None
-    if args.inflight > 1 and world == 1:
+    if args.inflight > 1 and not tiled_mode:
         import concurrent.futures as cf
         enc_n = pkg.CompressionPipeline(SETTINGS, device=local, slots=args.inflight)
         dec_n = pkg.DecompressionPipeline(device=local, slots=args.inflight, output="device")
@@ -367,7 +374,7 @@ def main():
         del enc_n, dec_n
 
     cpu, oracle_full = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not tiled_mode and not args.no_cpu_baseline:
         try:
             abi = importlib.import_module(PKG + "._abi")
             cpu, oracle_full = cpu_baseline(wl, frames[0], args.cpu_sample, abi.host_cpu_budget())
@@ -378,7 +385,7 @@ def main():
     # point-to-point D1 and luma PSNR of the decoded frame against the source, outside the timed region; for the HIP
     # reconstruction and for the CPU oracle's, which must be the same arrays
     quality = None
-    if rank == 0 and world == 1 and not args.no_psnr:
+    if rank == 0 and not tiled_mode and not args.no_psnr:
         metrics = importlib.import_module(PKG + ".metrics")
         t0 = time.time()
         quality = {"hip": metrics.frame_quality(frames[0], rec[0])}
@@ -395,7 +402,7 @@ def main():
 
     if rank == 0:
         frames_total = args.steps * world
-        if world == 1:
+        if not tiled_mode:
             workload = ("C2 ScanNet-scale 1M-point frame (BASELINE.json configs[1]): seeded indoor scene, 512x512x256 "
                         "grid, F=1 frame per GOP, Q=3 settings, hyperprior model demo_small; host numpy in (int16 points, "
                         "float64 colours) / host numpy out")

@@ -28,25 +28,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
 
 #define GC_WAVES 4
+#ifndef PCC_FIRST_DEPTH
+#define PCC_FIRST_DEPTH 8
+#endif
 
 #include "conv16.h"
 
-// The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound, and with one neighbour-index load and one gather
-// per offset in sequence every offset paid two dependent memory latencies.  All 27 neighbour indices of the tile are
-// fetched at once, and the rows of offset k+1 are in flight while offset k is contracted.  The gathered 32 x 4 tile
-// goes through a wave-private LDS tile (pitch 5 floats: conflict-free) into the MFMA B operand; the 13.8 KB of weights
-// sit in LDS (one load per workgroup; as two dword loads per offset and wave they were half of the kernel's loads); the
-// product is computed transposed (D[co][row]) so that a lane stores 16 B at a time: 105 -> 89 us.  Tried and slower:
-// 64-row windows without the LDS tile (registers), index loads split between the two half-waves (14 full-wave loads
-// + v_permlane32_swap instead of 27 half-wave ones: 103 us).
+// The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound (252 MB: 108 MB of rule book, 128 MB of output).
+// One wave per 32-row tile, the product computed transposed (D[co][row] = W^T X^T) so that a lane ends up with 16
+// channels of one row and stores 16 B at a time.  All 27 neighbour indices of the tile are fetched at once;
+// PCC_FIRST_DEPTH row gathers are in flight ahead of the offset being contracted.  Both half-waves fetch the same 32
+// rows (same lines, one request each) and a lane keeps the two input channels it feeds to the B operand (K index =
+// lane >> 5) — no LDS transpose and no wave barrier in the step.  The 13.8 KB of weights sit in LDS (one load per
+// workgroup).  Offsets nobody in the tile has are skipped (11.7 of 27 are present on the bench frame).
+// 105 us (round 1: LDS tile, dword stores, weights from global, one gather ahead) -> 77 us.  Tried and slower: 64-row
+// windows (registers), index loads split between the half-waves (14 full-wave loads + v_permlane32_swap: +15 us).
 __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
     float* __restrict__ out) {
   constexpr int CIN = 4, NT = 1;
   constexpr int COUT = 32;
-  constexpr int PITCH = CIN + 1;
-  __shared__ float a_lds[GC_WAVES][32 * PITCH];
   __shared__ float w_lds[27 * CIN * COUT];   // 13.8 KB: one load per workgroup instead of two dword loads per offset and wave
   for (int t = threadIdx.x; t < k_vol * CIN * COUT; t += GC_WAVES * 64) w_lds[t] = w[t];
   __syncthreads();
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
   const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
   if (row0 >= n_out) return;  // wave-uniform
   const int i = lane & 31, h = lane >> 5;
-  float* a = a_lds[wave];
 
   f32x16 acc[NT];
 #pragma unroll
@@ -65,30 +66,27 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
     int32_t nbs[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) nbs[k] = (row_ok && k < k_vol) ? nbr[(int64_t)k * pitch + row0 + i] : -1;
+    // both half-waves fetch the same 32 rows (same lines: one request) and each keeps the two input channels it feeds
+    // to the MFMA B operand (K index = lane >> 5): no LDS transpose, no wave barriers in the step
     auto rows_of = [&](int32_t nb) -> float4 {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nb >= 0 && lane < 32) v = *reinterpret_cast<const float4*>(in + (int64_t)nb * CIN);
+      if (nb >= 0) v = *reinterpret_cast<const float4*>(in + (int64_t)nb * CIN);
       return v;
     };
-    float4 gn = rows_of(nbs[0]);
+    constexpr int D = PCC_FIRST_DEPTH;  // gathers in flight
+    float4 gq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) gq[d] = rows_of(nbs[d]);
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
-      const float4 gc = gn;
-      if (k + 1 < 27) gn = rows_of(nbs[k + 1]);  // -1 past k_vol: no load
+      const float4 gc = gq[k % D];
+      if (k + D < 27) gq[k % D] = rows_of(nbs[k + D]);  // -1 past k_vol: no load
       if (k < k_vol && __ballot(nbs[k] >= 0) != 0ull) {  // uniform: somebody in this tile has offset k
         const float wc0 = w_lds[(k * CIN + 0 + h) * COUT + i], wc1 = w_lds[(k * CIN + 2 + h) * COUT + i];
-        if (lane < 32) {
-          float* d = a + lane * PITCH;
-          d[0] = gc.x; d[1] = gc.y; d[2] = gc.z; d[3] = gc.w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float x0 = h ? gc.y : gc.x, x1 = h ? gc.w : gc.z;
         // transposed product D[co][row] = W^T x X^T: a lane ends up with 16 channels of ONE row (16-B stores below)
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc0, a[i * PITCH + 0 + h], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc1, a[i * PITCH + 2 + h], acc[0], 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc0, x0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc1, x1, acc[0], 0, 0, 0);
       }
     }
   }
