@@ -83,13 +83,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_count(
   __builtin_amdgcn_wave_barrier();
   if (wid < nw) {
     const int64_t t0 = wid * RS_WAVE_TILE;
-#pragma unroll 4
+    uint64_t kk[RS_ROUNDS];  // all of the tile's keys in flight before the first LDS atomic
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
-      int64_t e = t0 + r * 64 + lane;
-      if (e < n) {
-        uint32_t d = (uint32_t)(((keys[e] ^ flip) >> shift) & 255u);
-        atomicAdd(&cnt[wave][d], 1u);
-      }
+      const int64_t e = t0 + r * 64 + lane;
+      kk[r] = e < n ? keys[e] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+      const int64_t e = t0 + r * 64 + lane;
+      if (e < n) atomicAdd(&cnt[wave][(uint32_t)(((kk[r] ^ flip) >> shift) & 255u)], 1u);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -110,15 +113,22 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
   __builtin_amdgcn_wave_barrier();
   const int64_t t0 = wid * RS_WAVE_TILE;
   const uint64_t lanes_below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // the tile's keys and values are requested up front: the rounds below are serial through base[] (LDS), and with one
+  // load per round each of them paid a full memory latency (16 per wave; the launch has ~1 wave per SIMD)
+  uint64_t keys[RS_ROUNDS];
+  uint32_t vals[RS_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int64_t e = t0 + r * 64 + lane;
+    keys[r] = e < n ? keys_in[e] : 0ull;
+    vals[r] = (e < n && vals_in) ? vals_in[e] : (uint32_t)e;
+  }
+#pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
     const int64_t e = t0 + r * 64 + lane;
     const bool valid = e < n;
-    uint64_t key = 0;
-    uint32_t val = 0;
-    if (valid) {
-      key = keys_in[e];
-      val = vals_in ? vals_in[e] : (uint32_t)e;
-    }
+    const uint64_t key = keys[r];
+    const uint32_t val = vals[r];
     const uint32_t d = (uint32_t)(((key ^ flip) >> shift) & 255u);
     uint64_t mask = __ballot(valid);
 #pragma unroll
