@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <exception>
@@ -252,7 +253,9 @@ struct pcc_codec {
   pcc_rans_dev *gc_dev = nullptr, *eb_dev = nullptr;  // the two CDF sets in HBM for the GPU coder
   PccWorkers workers;                  // the Q coder threads of the encoder
   DevPool pool;
-  Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec;
+  Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec, pin_up;
+  hipStream_t up_stream = nullptr;     // host frames cross PCIe on this stream while the compute stream sorts (encode_gop_impl)
+  hipEvent_t up_done = nullptr;
   std::deque<CS> sets;
   std::vector<std::vector<uint8_t>> out;  // containers of the last encode
   // reconstruction of the last decode (device, pool-owned: valid until the next call)
@@ -809,7 +812,13 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
   pcc_rans_dev_destroy(cd->gc_dev);
   pcc_rans_dev_destroy(cd->eb_dev);
   cd->pool.release();
-  for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec})
+  if (cd->up_stream) {
+    (void)hipStreamSynchronize(cd->up_stream);
+    (void)hipStreamDestroy(cd->up_stream);
+  }
+  if (cd->up_done) (void)hipEventDestroy(cd->up_done);
+  for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec,
+                    &cd->pin_up})
     p->release();
   pcc_destroy(cd->ctx);
   delete cd;
@@ -880,6 +889,57 @@ __global__ __launch_bounds__(256) void k_frames_feats(FrameTab t, const uint32_t
   feats[i] = make_float4(1.0f, r, g, b);
 }
 
+// ---- host frames -> HBM (pcc_encode_gop_host_frames).  The frame arrays are pageable numpy memory; handed to
+// hipMemcpyAsync as they are, the runtime stages them 1 MB at a time on the calling thread (24 MB of float64 colours:
+// 1.0 ms at 24 GB/s, and the GPU waits for them behind the sort).  Here the codec's parked threads write the arrays into
+// a pinned staging buffer laid out like the device copy — the colours CONVERTED to float32 on the way (the cast
+// unpack_batch does, codec_pipeline.py:243-262; same round-to-nearest conversion as the device's, half the bytes over
+// PCIe) — and each piece goes up by DMA on a stream of its own as soon as it is written.
+struct UploadPiece {
+  size_t off;      // byte offset in the staging region == in the device region
+  const void* src;
+  size_t count;    // bytes (raw) or elements (f64 -> f32)
+  int f64;
+};
+constexpr int kUploadThreads = 4;
+constexpr size_t kUploadPieceBytes = (size_t)1 << 20;  // of staged output
+
+static void upload_pieces(std::vector<UploadPiece>* out, size_t base, const void* src, size_t n_bytes_out, int f64) {
+  for (size_t o = 0; o < n_bytes_out; o += kUploadPieceBytes) {
+    const size_t len = std::min(kUploadPieceBytes, n_bytes_out - o);
+    if (f64)
+      out->push_back({base + o, (const double*)src + o / 4, len / 4, 1});
+    else
+      out->push_back({base + o, (const char*)src + o, len, 0});
+  }
+}
+
+// runs the pieces on the parked threads: piece i on thread i % kUploadThreads; with `stream` every thread sends its
+// piece up as soon as it is staged (dev + off <- staging + off); *status collects the first HIP error
+static void upload_run(pcc_codec* cd, const std::vector<UploadPiece>& pieces, char* stage, char* dev, hipStream_t stream,
+                       std::atomic<int>* status) {
+  cd->workers.ensure(kUploadThreads);
+  const int device = cd->device;
+  for (int w = 0; w < kUploadThreads; ++w)
+    cd->workers.run(w, [&pieces, stage, dev, stream, status, device, w]() {
+      if (stream && hipSetDevice(device) != hipSuccess) status->store(1);
+      for (size_t i = (size_t)w; i < pieces.size(); i += kUploadThreads) {
+        const UploadPiece& p = pieces[i];
+        size_t bytes = p.count;
+        if (p.f64) {
+          float* d = (float*)(stage + p.off);
+          const double* sp = (const double*)p.src;
+          for (size_t j = 0; j < p.count; ++j) d[j] = (float)sp[j];
+          bytes = p.count * 4;
+        } else {
+          memcpy(stage + p.off, p.src, p.count);
+        }
+        if (stream && hipMemcpyAsync(dev + p.off, stage + p.off, bytes, hipMemcpyHostToDevice, stream) != hipSuccess)
+          status->store(1);
+      }
+    });
+}
+
 static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* d_feats, int64_t n, int n_frames,
                            const double* h_q, int n_q, pcc_buf* h_out, int64_t* h_k, double* h_stage_s,
                            const FrameTab* frames_in = nullptr, const HostFrames* host = nullptr) {
@@ -908,23 +968,49 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_HIP(hipMemsetAsync(flag, 0, 4, st));
     FrameTab ftab;
     const FrameTab* frames = frames_in;
+    std::vector<UploadPiece> col_pieces;
+    std::atomic<int> up_status{0};
+    struct WaitWorkers {  // the upload jobs read this frame's locals: no way out of the block with one of them running
+      PccWorkers* w = nullptr;
+      ~WaitWorkers() { if (w) w->wait_all(); }
+    } up_guard;
+    char* dc = nullptr;
+    size_t pts_bytes = 0;
     if (host) {
       // the frame arrays are host memory: points first (6 B per point), keys + sort are queued behind them, and the
-      // colours (24 B per point as float64) cross PCIe while the GPU sorts
+      // colours (float32 from here on) cross PCIe on cd->up_stream while the GPU sorts and builds the rule books
+      if (!cd->up_stream) {
+        PCC_HIP(hipStreamCreateWithFlags(&cd->up_stream, hipStreamNonBlocking));
+        PCC_HIP(hipEventCreateWithFlags(&cd->up_done, hipEventDisableTiming));
+      }
+      PCC_HIP(hipStreamSynchronize(cd->up_stream));  // idle unless the previous call left early
       ftab = *frames_in;
-      const size_t pb = ftab.pts_i16 ? 6 : 12, cb = ftab.cols_f64 ? 24 : 12;
+      const size_t pb = ftab.pts_i16 ? 6 : 12, cb = 12;
       char* dp = (char*)cd->pool.alloc((size_t)n * pb + 256 * (size_t)ftab.nf);
-      char* dc = (char*)cd->pool.alloc((size_t)n * cb + 256 * (size_t)ftab.nf);
+      dc = (char*)cd->pool.alloc((size_t)n * cb + 256 * (size_t)ftab.nf);
       if (!dp || !dc) return PCC_E_NOMEM;
+      std::vector<UploadPiece> pt_pieces;
       size_t po = 0, co = 0;
       for (int f = 0; f < ftab.nf; ++f) {
         const size_t nf = (size_t)(ftab.off[f + 1] - ftab.off[f]);
         ftab.pts[f] = dp + po;
-        ftab.cols[f] = dc + co;
-        if (nf) PCC_HIP(hipMemcpyAsync(dp + po, host->pts[f], nf * pb, hipMemcpyHostToDevice, st));
+        upload_pieces(&pt_pieces, po, host->pts[f], nf * pb, 0);
         po += (nf * pb + 255) & ~(size_t)255;
+      }
+      pts_bytes = po;
+      for (int f = 0; f < ftab.nf; ++f) {  // colours staged behind the points
+        const size_t nf = (size_t)(ftab.off[f + 1] - ftab.off[f]);
+        ftab.cols[f] = dc + co;
+        upload_pieces(&col_pieces, co, host->cols[f], nf * cb, ftab.cols_f64);
         co += (nf * cb + 255) & ~(size_t)255;
       }
+      ftab.cols_f64 = 0;
+      PCC_TRY(cd->pin_up.ensure(pts_bytes + co));
+      up_guard.w = &cd->workers;
+      upload_run(cd, pt_pieces, (char*)cd->pin_up.p, nullptr, nullptr, &up_status);
+      cd->workers.wait_all();
+      if (po) PCC_HIP(hipMemcpyAsync(dp, cd->pin_up.p, po, hipMemcpyHostToDevice, st));
+      upload_run(cd, col_pieces, (char*)cd->pin_up.p + pts_bytes, dc, cd->up_stream, &up_status);
       frames = &ftab;
     }
     if (frames) {
@@ -934,13 +1020,6 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
     }
     PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
-    if (host) {  // the colours, while the sort runs (a pageable source blocks this thread, not the GPU)
-      const size_t cb = frames->cols_f64 ? 24 : 12;
-      for (int f = 0; f < frames->nf; ++f) {
-        const size_t nf = (size_t)(frames->off[f + 1] - frames->off[f]);
-        if (nf) PCC_HIP(hipMemcpyAsync(const_cast<void*>(frames->cols[f]), host->cols[f], nf * cb, hipMemcpyHostToDevice, st));
-      }
-    }
     PCC_TRY(cd->pin_flag.ensure(64));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
     // one read-back for the duplicate check and the sizes of the five pyramid levels above the input (g_a: strides
@@ -952,6 +1031,19 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE,
                 "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0,65534]");
     PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_encode_gop: duplicate coordinates");
+    x = {new_set(cd, keys, n, 1, n_frames), f, 4};
+    x.cs->down_counts = level_n;
+    if (host) {
+      // the pyramid and the rule book of the input level need coordinates only: queued in front of the feature rows,
+      // they run while the last colours are on their way
+      int32_t* nbr0;
+      PCC_TRY(nbr27_of(cd, x.cs, &nbr0));
+      cd->workers.wait_all();
+      up_guard.w = nullptr;
+      PCC_REQUIRE(up_status.load() == 0, PCC_E_HIP, "pcc_encode_gop_host_frames: upload of the frame arrays failed");
+      PCC_HIP(hipEventRecord(cd->up_done, cd->up_stream));
+      PCC_HIP(hipStreamWaitEvent(st, cd->up_done, 0));
+    }
     if (frames) {
       hipLaunchKernelGGL(k_frames_feats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *frames,
                          (const uint32_t*)perm, n, (float4*)f);
@@ -959,8 +1051,6 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     } else {
       PCC_TRY(pcc_gather_rows(ctx, d_feats, perm, n, 16, f));
     }
-    x = {new_set(cd, keys, n, 1, n_frames), f, 4};
-    x.cs->down_counts = level_n;
   }
 
   // ---- step 1: analysis g_a + canonical order of y (codec_pipeline.py:270-281)
