@@ -870,6 +870,15 @@ __global__ __launch_bounds__(256) void k_frames_keys(FrameTab t, int64_t n, uint
   keys[i] = pcc_morton(f, x, y, z);
 }
 
+// first and last sorted key of every frame (frames stay contiguous under the sort: the frame index is the top of the key)
+__global__ void k_frame_end_keys(FrameTab t, const uint64_t* __restrict__ keys, uint64_t* __restrict__ out) {
+  const int f = threadIdx.x;
+  if (f >= t.nf) return;
+  const bool any = t.off[f + 1] > t.off[f];
+  out[2 * f] = any ? keys[t.off[f]] : 0ull;
+  out[2 * f + 1] = any ? keys[t.off[f + 1] - 1] : 0ull;
+}
+
 // feature row i of the Morton-sorted tensor = (1, r, g, b) of concatenated row perm[i]
 __global__ __launch_bounds__(256) void k_frames_feats(FrameTab t, const uint32_t* __restrict__ perm, int64_t n,
                                                       float4* __restrict__ feats) {
@@ -960,6 +969,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
 
   // ---- unpack_batch: SparseTensor(coordinates, features) -> Morton-sorted rows
   Feat x;
+  std::vector<uint64_t> root_keys;  // first / last input key of every frame, when the frames came as a table
   {
     CODEC_ALLOC(keys, uint64_t, n);
     CODEC_ALLOC(flag, int32_t, 1);
@@ -1020,8 +1030,14 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
     }
     PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
-    PCC_TRY(cd->pin_flag.ensure(64));
+    PCC_TRY(cd->pin_flag.ensure(64 + 16 * PCC_MAX_FRAMES_ARG));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
+    if (frames) {  // the octree roots of the geometry slots follow from these (octree_root drops the low 9 key bits)
+      CODEC_ALLOC(ends, uint64_t, 2 * PCC_MAX_FRAMES_ARG);
+      hipLaunchKernelGGL(k_frame_end_keys, dim3(1), dim3(PCC_MAX_FRAMES_ARG), 0, st, *frames, (const uint64_t*)keys, ends);
+      PCC_CHECK_LAUNCH();
+      PCC_HIP(hipMemcpyAsync(cd->pin_flag.p + 64, ends, (size_t)16 * frames->nf, hipMemcpyDeviceToHost, st));
+    }
     // one read-back for the duplicate check and the sizes of the five pyramid levels above the input (g_a: strides
     // 2, 4, 8; h_a: 16, 32), instead of one per level
     int dup = 0;
@@ -1031,6 +1047,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE,
                 "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0,65534]");
     PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_encode_gop: duplicate coordinates");
+    if (frames) root_keys.assign((const uint64_t*)(cd->pin_flag.p + 64), (const uint64_t*)(cd->pin_flag.p + 64) + 2 * frames->nf);
     x = {new_set(cd, keys, n, 1, n_frames), f, 4};
     x.cs->down_counts = level_n;
     if (host) {
@@ -1092,8 +1109,54 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   };
   std::vector<FrameGeo> geo((size_t)n_frames);
   double geo_dev_s = 0;
+  // Asynchronous form — every frame's latent within the single-workgroup octree kernel and the frames' end keys on the
+  // host since the sort: the octree kernels and the transfers of their output are queued and an event recorded, nothing
+  // waits.  The occupancy bytes come down as a guess of 2 bytes per leaf (a surface latent has ~1.3; the rest follows
+  // if a frame has more).  geometry_finish() waits for the event.
+  bool geo_async = false;
+  Event geo_ev;
+  uint8_t* geo_occ_dev = nullptr;
+  std::vector<int64_t> geo_cap((size_t)n_frames, 0), geo_got((size_t)n_frames, 0);
+  constexpr int kGeoCounts = 20;  // uint32 per frame in the counts block (depth + 1 <= 17 used)
   auto geometry_device_half = [&]() -> int {
     const double tg = now_s();
+    bool small = (int)root_keys.size() == 2 * n_frames;
+    for (int f = 0; f < n_frames; ++f) small &= (*yoffs)[f + 1] - (*yoffs)[f] <= pcc_octree_small_max();
+    if (small) {
+      int64_t cap_total = 0;
+      for (int f = 0; f < n_frames; ++f) {
+        FrameGeo& g = geo[f];
+        g.n = (*yoffs)[f + 1] - (*yoffs)[f];
+        g.depth = 0;
+        g.occ_off = cap_total;
+        g.occ_len = 0;
+        g.origin[0] = g.origin[1] = g.origin[2] = 0;
+        if (g.n > 0) {
+          octree_root(root_keys[2 * f], root_keys[2 * f + 1], 9, &g.depth, g.origin);
+          geo_cap[f] = (g.n * g.depth + 255) & ~(int64_t)255;
+          cap_total += geo_cap[f];
+        }
+      }
+      CODEC_ALLOC(occ, uint8_t, std::max<int64_t>(cap_total, 1));
+      CODEC_ALLOC(cnt, uint32_t, kGeoCounts * n_frames);
+      geo_occ_dev = occ;
+      PCC_TRY(cd->pin_occ.ensure((size_t)std::max<int64_t>(cap_total, 1)));
+      PCC_TRY(cd->pin_keys.ensure((size_t)kGeoCounts * 4 * n_frames));
+      if (!geo_ev.e) PCC_TRY(geo_ev.create());
+      for (int f = 0; f < n_frames; ++f) {
+        FrameGeo& g = geo[f];
+        if (g.n == 0) continue;
+        PCC_TRY(pcc_octree_small_async(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, occ + g.occ_off, geo_cap[f],
+                                       cnt + kGeoCounts * f));
+        geo_got[f] = std::min<int64_t>(geo_cap[f], (2 * g.n + 255) & ~(int64_t)255);
+        PCC_HIP(hipMemcpyAsync(cd->pin_occ.p + g.occ_off, occ + g.occ_off, (size_t)geo_got[f], hipMemcpyDeviceToHost, st));
+      }
+      PCC_HIP(hipMemcpyAsync(cd->pin_keys.p, cnt, (size_t)kGeoCounts * 4 * n_frames, hipMemcpyDeviceToHost, st));
+      PCC_HIP(hipEventRecord(geo_ev.e, st));
+      geo_async = true;
+      geo_dev_s = now_s() - tg;
+      return PCC_OK;
+    }
     PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 8));
     if (ny > 0) PCC_HIP(hipMemcpyAsync(cd->pin_keys.p, y.cs->keys, (size_t)ny * 8, hipMemcpyDeviceToHost, st));
     PCC_HIP(hipStreamSynchronize(st));
@@ -1124,6 +1187,32 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     }
     PCC_HIP(hipStreamSynchronize(st));  // occupancy bytes and (earlier in the stream) the z symbols are on the host
     geo_dev_s = now_s() - tg;
+    return PCC_OK;
+  };
+  // the device half has arrived (asynchronous form): level counts, and the occupancy bytes the guess did not cover
+  auto geometry_arrived = [&]() -> int {
+    if (!geo_async) return PCC_OK;
+    PCC_HIP(hipEventSynchronize(geo_ev.e));
+    const uint32_t* hc = (const uint32_t*)cd->pin_keys.p;
+    bool more = false;
+    for (int f = 0; f < n_frames; ++f) {
+      FrameGeo& g = geo[f];
+      if (g.n == 0) continue;
+      g.level_n.assign((size_t)g.depth, 0);
+      for (int L = 0; L < g.depth; ++L) {
+        g.level_n[L] = (int64_t)hc[kGeoCounts * f + L];
+        g.occ_len += g.level_n[L];
+      }
+      PCC_REQUIRE(g.level_n[0] == 1 && g.occ_len <= g.n * g.depth, PCC_E_ARG,
+                  "pcc_encode_gop: octree of frame %d: %lld root nodes, %lld nodes for %lld leaves", f,
+                  (long long)g.level_n[0], (long long)g.occ_len, (long long)g.n);
+      if (g.occ_len > geo_got[f]) {
+        PCC_HIP(hipMemcpyAsync(cd->pin_occ.p + g.occ_off + geo_got[f], geo_occ_dev + g.occ_off + geo_got[f],
+                               (size_t)(g.occ_len - geo_got[f]), hipMemcpyDeviceToHost, st));
+        more = true;
+      }
+    }
+    if (more) PCC_HIP(hipStreamSynchronize(st));
     return PCC_OK;
   };
 
@@ -1168,8 +1257,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
                *eb_off = find(cd, "entropy_bottleneck.offset");
   PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_encode_gop: entropy_bottleneck tables missing");
-  auto geometry_slots = [&]() -> int {
-    PCC_TRY(geometry_device_half());
+  auto geometry_finish = [&]() -> int {
+    PCC_TRY(geometry_arrived());
     const double t = now_s();
     for (int f = 0; f < n_frames; ++f) {
       const FrameGeo& g = geo[f];
@@ -1185,7 +1274,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     return PCC_OK;
   };
   auto side_streams = [&]() -> int {
-    PCC_TRY(geometry_slots());
+    PCC_TRY(geometry_device_half());
+    PCC_TRY(geometry_finish());
     double t = now_s();
     std::vector<int32_t> idx((size_t)nz * cz);
     for (int c = 0; c < cz; ++c) std::fill(idx.begin() + (size_t)c * nz, idx.begin() + (size_t)(c + 1) * nz, c);
@@ -1229,6 +1319,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     long long* h_lens = (long long*)cd->pin_flag.p;
     uint8_t *ystreams = nullptr, *zstream = nullptr;
     int64_t cap_y = 0, cap_z = 0;
+    PCC_TRY(geometry_device_half());  // queued in front of the coder kernels: its output is on the host while they run
     for (int attempt = 0; attempt < 2; ++attempt) {
       // attempt 0: 6 bytes per symbol of room (the coder's own first attempt holds 1.5 words per symbol); attempt 1: the bound
       cap_y = attempt == 0 ? std::min<int64_t>(pcc_rans_dev_bound(per), (6 * per + 65536) / 4 * 4) : pcc_rans_dev_bound(per);
@@ -1240,8 +1331,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_TRY(pcc_rans_encode_dev_async(ctx, cd->eb_dev, zsym_dev, nullptr, std::max<int64_t>(nz, 1), nzs, 1, zstream, cap_z,
                                         d_lens + n_q, attempt));
       PCC_HIP(hipMemcpyAsync(h_lens, d_lens, (size_t)(n_q + 1) * 8, hipMemcpyDeviceToHost, st));
-      if (attempt == 0) PCC_TRY(geometry_slots());   // its synchronisation also lands the lengths
-      else PCC_HIP(hipStreamSynchronize(st));
+      if (attempt == 0) PCC_TRY(geometry_finish());   // the occupancy coder of this thread runs while the GPU codes
+      PCC_HIP(hipStreamSynchronize(st));
       bool fits = true;
       for (int q = 0; q <= n_q; ++q) fits &= h_lens[q] >= 0;
       if (fits) break;

@@ -202,6 +202,24 @@ __global__ __launch_bounds__(OCT_T) void k_oct_small(const uint64_t* __restrict_
     for (uint32_t j = tid; j < words; j += OCT_T) occ32[j] = s_occ[j];
 }
 
+// Internal (codec.hip): the single-workgroup form alone and nothing read back — the levels packed root-first into
+// d_occ (4-byte aligned, cap_s bytes), the node counts of levels 0 .. depth-1 and the leaf count into
+// d_counts[depth + 1].  A total above cap_s leaves d_occ untouched; the caller sees it in the counts.
+int pcc_octree_small_max() { return OCT_SMALL_MAX; }
+int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,
+                           int64_t cap_s, uint32_t* d_counts) {
+  PCC_REQUIRE(ctx && d_keys && d_occ && d_counts && n >= 1 && n <= OCT_SMALL_MAX && depth >= 1 && depth <= 16 &&
+                  key_shift >= 0 && key_shift % 3 == 0 && key_shift + 3 * depth <= 48 && cap_s >= 4 &&
+                  cap_s < ((int64_t)1 << 31) && (uintptr_t)d_occ % 4 == 0,
+              PCC_E_ARG, "pcc_octree_small_async: bad argument (n=%lld depth=%d)", (long long)n, depth);
+  PccProfScope prof(ctx, "octree_levels", n, depth, 0, 0);
+  const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
+  hipLaunchKernelGGL(k_oct_small, dim3(1), dim3(OCT_T), 0, ctx->stream, d_keys, (int)n, key_shift, leaf_mask, depth,
+                     (uint32_t*)d_occ, (int)cap_s, d_counts);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift,
                                  int depth, uint8_t* d_occ, int64_t cap, int64_t* h_level_n) {
   PCC_REQUIRE(ctx && h_level_n, PCC_E_ARG, "pcc_octree_levels: null arg");
