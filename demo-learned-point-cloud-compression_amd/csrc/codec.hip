@@ -1848,6 +1848,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     const std::vector<int64_t>* o0;
     PCC_TRY(offsets_of(cd, h.cs, &o0));
   }
+  const float* rgb_cand = nullptr;  // colours of the last stage's candidate rows, when its conv evaluated the colour head
   for (int j = 0; j < 3; ++j) {
     const std::string uname = "g_s.up" + std::to_string(j);
     const std::string cname = "g_s.conv" + std::to_string(j), oname = "g_s.occ" + std::to_string(j);
@@ -1861,9 +1862,25 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     Feat u;
     PCC_TRY(up2(cd, uname, h, 1, &u, fused));
     const int64_t nu = u.cs->n;
-    CODEC_ALLOC(feats, float, std::max<int64_t>(nu, 1) * cout);
+    // last stage: only the occupancy logit and the colour of a candidate row are ever read again, so the conv evaluates
+    // the colour head on every candidate row too and does not store the rows (128 B each) at all
+    const Tensor* tcol = find(cd, "g_s.color.weight");
+    const bool with_rgb = fused && j == 2 && nu > 0 && tcol && tcol->dims.size() == 2 && tcol->dims[0] == 32 &&
+                          tcol->dims[1] == 3;
+    float* feats = nullptr;
+    if (!with_rgb) {
+      feats = (float*)cd->pool.alloc(sizeof(float) * (size_t)(std::max<int64_t>(nu, 1) * cout));
+      if (!feats) return PCC_E_NOMEM;
+    }
     CODEC_ALLOC(logits, float, std::max<int64_t>(nu, 1));
-    if (fused && nu > 0) {
+    if (with_rgb) {
+      int32_t* pn;
+      PCC_TRY(nbr27_of(cd, h.cs, &pn));
+      CODEC_ALLOC(rgb_all, float, nu * 3);
+      rgb_cand = rgb_all;
+      PCC_TRY(pcc_sparse_conv_head_up_perm_rgb(ctx, u.f, h.cs->n, pn, h.cs->n, w, b, 1, hw, hb, logits,
+                                               cd->dev["g_s.color.weight"], cd->dev["g_s.color.bias"], rgb_all));
+    } else if (fused && nu > 0) {
       // rule book of the 8N candidates formed inside the conv from the book of the N rows below
       int32_t* pn;
       PCC_TRY(nbr27_of(cd, h.cs, &pn));
@@ -1909,7 +1926,9 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     CODEC_ALLOC(rgb, float, std::max<int64_t>(nr, 1) * 3);
     CODEC_ALLOC(coords, int32_t, std::max<int64_t>(nr, 1) * 4);
     if (nr > 0) {
-      if (h.rows && (int)tw->dims[0] == 32 && (int)tw->dims[1] <= 8)
+      if (rgb_cand && h.rows)
+        PCC_TRY(pcc_gather_rows(ctx, rgb_cand, h.rows, nr, 12, rgb));
+      else if (h.rows && (int)tw->dims[0] == 32 && (int)tw->dims[1] <= 8)
         PCC_TRY(pcc_linear_gather(ctx, h.f, h.rows, nr, w, b, (int)tw->dims[1], 0, rgb));
       else if (h.rows) {  // a head the fused form does not cover: gather first
         CODEC_ALLOC(pf, float, nr * h.c);

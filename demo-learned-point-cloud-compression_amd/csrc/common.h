@@ -85,6 +85,10 @@ void pcc_wcache_free(pcc_ctx* ctx);
 int pcc_octree_small_max();
 int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,
                            int64_t cap_s, uint32_t* d_counts);
+int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent,
+                                     int64_t parent_pitch, const float* d_w, const float* d_bias, int relu,
+                                     const float* d_head_w, const float* d_head_b, float* d_head_out,
+                                     const float* d_rgb_w, const float* d_rgb_b, float* d_rgb_out);
 int pcc_sparse_conv_head_up_perm(pcc_ctx* ctx, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent,
                                  int64_t parent_pitch, const float* d_w, const float* d_bias, int relu, float* d_out,
                                  const float* d_head_w, const float* d_head_b, float* d_head_out);

@@ -359,9 +359,9 @@ static int weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cout, cons
 template <bool HEAD, bool UP, bool PERM, int COUT>
 static void launch16(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch, int64_t n_out,
                      const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
-                     float* ho) {
+                     float* ho, const float* cw = nullptr, const float* cb = nullptr, float* co = nullptr) {
   hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT>), dim3((nblk(n_out, 64) + 7) / 8 * 8, COUT / 32), dim3(64), 0, st,
-                     d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho);
+                     d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
 }
 
 static bool conv16_shape(const float* d_in, const float* d_out, int k_vol, int cin, int cout) {
@@ -468,6 +468,30 @@ int pcc_sparse_conv_head_up_perm(pcc_ctx* ctx, const float* d_in, int64_t n_pare
                                  const float* d_head_w, const float* d_head_b, float* d_head_out) {
   return head_up_impl(ctx, d_in, n_parents, d_nbr_parent, parent_pitch, d_w, d_bias, relu, d_out, d_head_w, d_head_b,
                       d_head_out, true);
+}
+
+// internal (common.h): the last stage of g_s — the same layer with the 32 -> 3 colour head evaluated on every candidate
+// row as well (bit-identical to pcc_linear on the stored rows) and the rows themselves NOT stored: after the pruning
+// only their occupancy logit and their colour are ever read, so 128 B per candidate row stay out of HBM.
+int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent,
+                                     int64_t parent_pitch, const float* d_w, const float* d_bias, int relu,
+                                     const float* d_head_w, const float* d_head_b, float* d_head_out,
+                                     const float* d_rgb_w, const float* d_rgb_b, float* d_rgb_out) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv_head_up_perm_rgb: null ctx");
+  if (n_parents <= 0) return PCC_OK;
+  PCC_REQUIRE(d_in && d_nbr_parent && d_w && d_bias && d_head_w && d_head_b && d_head_out && d_rgb_w && d_rgb_b &&
+                  d_rgb_out && parent_pitch >= n_parents && n_parents < ((int64_t)1 << 27) && (uintptr_t)d_in % 16 == 0,
+              PCC_E_ARG, "pcc_sparse_conv_head_up_perm_rgb: bad buffers (pitch %lld, parents %lld)",
+              (long long)parent_pitch, (long long)n_parents);
+  PCC_REQUIRE(pcc_conv_up_fused(), PCC_E_ARG, "pcc_sparse_conv_head_up_perm_rgb: only the MFMA kernel has this form");
+  const int64_t n_out = 8 * n_parents;
+  const float* wsw;
+  PCC_TRY(weights_for(ctx, d_w, 27, 32, &wsw));
+  PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
+  launch16<true, true, true, 32>(ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, nullptr,
+                                 d_head_w, d_head_b, d_head_out, d_rgb_w, d_rgb_b, d_rgb_out);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
 }
 
 extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, const float* d_w,

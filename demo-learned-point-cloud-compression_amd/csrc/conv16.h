@@ -91,7 +91,8 @@ __global__ __launch_bounds__(64) void k_gconv16(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
     float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
-    float* __restrict__ head_out) {
+    float* __restrict__ head_out, const float* __restrict__ rgb_w = nullptr, const float* __restrict__ rgb_b = nullptr,
+    float* __restrict__ rgb_out = nullptr) {
   constexpr int R = 64;    // rows of the window
   // Accumulators in LDS: two planes (channels 0..15, 16..31) of 16-float rows; the 16-B piece q of a row sits at
   // position (q + 2 (row >> 2)) & 3 of its plane row.  The hardware serves a ds_read_b128 / ds_write_b128 in groups of 16
@@ -316,7 +317,9 @@ __global__ __launch_bounds__(64) void k_gconv16(
   }
 #endif
 
-  // ---- epilogue: the window's rows are contiguous in `out`: coalesced 16-B stores
+  // ---- epilogue: the window's rows are contiguous in `out`: coalesced 16-B stores (out == nullptr with the colour
+  // head below: the last stage of g_s, whose rows nothing else reads)
+  if (out != nullptr)
 #pragma unroll
   for (int it = 0; it < R / 8; ++it) {
     const int r = it * 8 + grow;
@@ -340,5 +343,27 @@ __global__ __launch_bounds__(64) void k_gconv16(
       }
     }
     if (row_ok) head_out[r_own] = hv;
+    // the 1x1 colour head of g_s (32 -> 3, no activation) on the same rows: rgb[j] = b[j]; c ascending: fmaf(x[c],
+    // w[c][j], rgb[j]) — the chain of pcc_linear; the rows themselves then never leave the LDS
+    if (rgb_out != nullptr) {
+      float cv[3] = {rgb_b[0], rgb_b[1], rgb_b[2]};
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, lane, c4 & 3)]);
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = vv[j];
+          if (relu) v = fmaxf(v, 0.f);
+#pragma unroll
+          for (int o = 0; o < 3; ++o) cv[o] = fmaf(v, rgb_w[(4 * c4 + j) * 3 + o], cv[o]);
+        }
+      }
+      if (row_ok) {
+        rgb_out[3 * r_own] = cv[0];
+        rgb_out[3 * r_own + 1] = cv[1];
+        rgb_out[3 * r_own + 2] = cv[2];
+      }
+    }
   }
 }
