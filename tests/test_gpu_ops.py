@@ -69,6 +69,37 @@ def test_sort_pairs_matches_stable_argsort(rt, n):
     assert np.array_equal(u64(k), keys[ref])
 
 
+@pytest.mark.parametrize("case", ["few_high_parts", "many_high_parts", "one_high_part", "signed_few", "straddling_zero"])
+def test_sort_pairs_multi_kernel_path(rt, oracle, case):
+    """n above the single-workgroup limit: the multi-kernel radix passes (constant bytes skipped), stable in every case
+    (repeated keys keep their input order)"""
+    rng = np.random.default_rng(len(case))
+    n = 150_001
+    signed = case == "signed_few"
+    low = rng.integers(0, 1 << 24, n).astype(np.uint64)
+    low[::7] = low[0]                                   # repeated keys
+    if case == "few_high_parts":
+        hi = rng.choice(rng.integers(0, 1 << 38, 200), n).astype(np.uint64)
+    elif case == "many_high_parts":
+        hi = rng.integers(0, 1 << 38, n).astype(np.uint64)
+    elif case == "one_high_part":
+        hi = np.full(n, 0x12345, np.uint64)
+    elif case == "signed_few":
+        hi = rng.choice(np.array([0, 1, 5, (1 << 40) - 1, (1 << 40) - 9, 1 << 39], np.uint64), n)
+    else:
+        pts = rng.integers(-300, 300, (n, 3))
+        c = np.concatenate([rng.integers(0, 3, (n, 1)), pts], 1).astype(np.int32)
+        keys = host(rt.morton_keys(dev(rt, c))).view(np.uint64)
+        hi = low = None
+    if hi is not None:
+        keys = (hi << np.uint64(24)) | low
+    ref = np.argsort(keys.view(np.int64) if signed else keys, kind="stable")
+    k = dev(rt, keys.view(np.int64))
+    perm = rt.sort_pairs(k, signed=signed)
+    assert np.array_equal(host(perm).view(np.uint32), ref.astype(np.uint32))
+    assert np.array_equal(u64(k), keys[ref])
+
+
 def test_sort_pairs_signed(rt):
     rng = np.random.default_rng(3)
     keys = rng.integers(-(1 << 62), 1 << 62, 5000, dtype=np.int64)
