@@ -88,6 +88,29 @@ def test_matches_oracle_on_fresh_input(enc, dec, oracle, wl):
         assert a["colors"].min() >= 0.0 and a["colors"].max() <= 1.0
 
 
+@pytest.mark.parametrize("version", [0, 1])
+def test_gops_of_changing_size_on_one_pipeline_pair(oracle, wl, version):
+    """tiny, small and medium GOPs one after the other through ONE encoder and ONE decoder (pools, pinned buffers and
+    staging grown by an earlier GOP are reused by a smaller one; on a tiny GOP the GPU finishes before the host looks,
+    on a larger one after): every container of every quality equals the oracle's, and the decoder — fed the ORACLE's
+    container, so that a fault is the decoder's — reproduces the oracle's frames (tools/soak_small.py is the long form)"""
+    cp, dp = pkg("codec_pipeline"), pkg("codec_parallel")
+    gops = [[wl.sphere_shell(24, 9.1, seed=6)], [wl.body(30000, seed=2)], [wl.sphere_shell(12, 4.0, seed=1)],
+            [wl.sphere_shell(40, 15.0, seed=5, offset=(3, -70, 11)), wl.body(20000, seed=3)]]
+    refs = []
+    for g in gops:
+        ref, _ = oracle.compress(g, SETTINGS, version=version)
+        refs.append((ref, oracle.decompress(ref[2])))
+    e = cp.CompressionPipeline(SETTINGS, slots=1, container_version=version)
+    d = dp.DecompressionPipeline(slots=1)
+    for _ in range(3):
+        for g, (ref, rec_ref) in zip(gops, refs):
+            out, _ = e.compress(wl.gop(copy_frames(g)))
+            assert [out[q] for q in (1, 2, 3)] == [ref[q] for q in (1, 2, 3)]
+            rec, _ = d.decompress(ref[2])
+            assert digest(rec) == digest(rec_ref)
+
+
 def test_sideinfo_contract(enc, dec, wl):
     """key names read downstream (receiver/client/client.py:160-177, evaluation/plot.py:102-121)"""
     gop = wl.gop([wl.sphere_shell(24, 9.1, seed=6)])
