@@ -144,6 +144,14 @@ def test_gop_of_two_large_frames_equals_oracle(codec, oracle, wl):
     check_oracle_parity(codec, oracle, wl, [wl.room(400_000, seed=5), wl.body(300_000, seed=6)])
 
 
+def test_single_frame_with_a_latent_beyond_the_small_kernels_equals_oracle(codec, oracle, wl):
+    """one 3M-voxel frame (the fused scan uncut): ~80k latent rows, past the single-workgroup octree / sort / order
+    kernels (65536 rows) — the geometry slot takes its level-by-level form, the y order its multi-kernel sort"""
+    frame = wl.fused_scan(3_000_000, seed=2)
+    assert frame["points"].shape[0] > 2_900_000
+    check_oracle_parity(codec, oracle, wl, [frame])
+
+
 def test_gop_with_ragged_frames(codec, wl):
     tiny = {"points": np.array([[5, -3, 9]], dtype=np.int16), "colors": np.array([[0.2, 0.4, 0.6]])}
     frames = [wl.sphere_shell(64, 25.2, seed=1), tiny, wl.room(120_000, seed=3), wl.sphere_shell(24, 9.1, seed=2,
