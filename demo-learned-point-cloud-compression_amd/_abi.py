@@ -49,6 +49,8 @@ PROTOTYPES = {
     "pcc_decode_gop": (i32, [vp, vp, i64, C.POINTER(PccCloudInfo), C.POINTER(C.c_double)]),
     "pcc_decode_fetch": (i32, [vp, vp, vp]),
     "pcc_decode_fetch_packed": (i32, [vp, vp, vp]),
+    "pcc_container_points": (i32, [vp, i64, vp, vp]),
+    "pcc_decode_gop_packed": (i32, [vp, vp, i64, vp, vp, i64, vp, vp]),
     "pcc_sparse_conv_head_up": (i32, [vp, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp, vp]),
     "pcc_gaussian_quant_dev": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp]),
     "pcc_rans_dev_create": (vp, [vp, i32, vp, vp, i32]),

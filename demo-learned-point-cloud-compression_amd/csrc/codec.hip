@@ -1534,8 +1534,17 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
 }
 
 // ---------------------------------------------------------------------------- decode
+// destinations of pcc_decode_gop_packed: the cloud as pack_batches returns it, queued behind the last kernel
+struct PackedDst {
+  int32_t* points;
+  float* colors;
+  int64_t cap;   // rows the two arrays hold
+};
+__global__ __launch_bounds__(256) void k_pack_cloud(const int4* __restrict__ coords, const float* __restrict__ colors,
+                                                    int64_t n, int32_t* __restrict__ xyz, float* __restrict__ rgb);
+
 static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_cloud_info* h_info,
-                           double* h_stage_s) {
+                           double* h_stage_s, const PackedDst* dst = nullptr) {
   PCC_REQUIRE(cd && cd->ctx, PCC_E_ARG, "pcc_decode_gop: null codec");
   PCC_REQUIRE(h_in && len >= 36 && h_info, PCC_E_STREAM, "pcc_decode_gop: container shorter than its header");
   pcc_ctx* ctx = cd->ctx;
@@ -1947,6 +1956,19 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     PCC_TRY(cd->pin_flag.ensure(64));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, d_status, 4, hipMemcpyDeviceToHost, st));
   }
+  if (dst && cd->rec_n > 0) {
+    // pcc_decode_fetch_packed's work, queued here: no synchronisation and no trip through the caller in between
+    const int64_t n = cd->rec_n;
+    PCC_REQUIRE(n <= dst->cap && dst->points && dst->colors, PCC_E_ARG,
+                "pcc_decode_gop_packed: %lld points decoded, destination holds %lld", (long long)n, (long long)dst->cap);
+    CODEC_ALLOC(xyz, int32_t, 3 * n);
+    CODEC_ALLOC(rgb3, float, 3 * n);
+    hipLaunchKernelGGL(k_pack_cloud, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int4*)cd->rec_coords,
+                       (const float*)cd->rec_colors, n, xyz, rgb3);
+    PCC_CHECK_LAUNCH();
+    PCC_HIP(hipMemcpyAsync(dst->points, xyz, (size_t)n * 12, hipMemcpyDefault, st));
+    PCC_HIP(hipMemcpyAsync(dst->colors, rgb3, (size_t)n * 12, hipMemcpyDefault, st));
+  }
   PCC_TRY(pcc_sync(ctx));
   if (v1 && *(volatile int32_t*)cd->pin_flag.p != 0) {
     cd->rec_n = 0;
@@ -2056,6 +2078,50 @@ extern "C" int pcc_decode_gop(pcc_codec* cd, const uint8_t* h_in, int64_t len, p
     pcc_set_error("pcc_decode_gop: %s", e.what());
     return PCC_E_STREAM;
   }
+}
+
+extern "C" int pcc_decode_gop_packed(pcc_codec* cd, const uint8_t* h_in, int64_t len, int32_t* points, float* colors,
+                                     int64_t cap_points, pcc_cloud_info* h_info, double* h_stage_s) {
+  PCC_REQUIRE(points && colors && cap_points >= 0, PCC_E_ARG, "pcc_decode_gop_packed: null destination");
+  const PackedDst dst{points, colors, cap_points};
+  try {
+    return decode_gop_impl(cd, h_in, len, h_info, h_stage_s, &dst);
+  } catch (const std::bad_alloc&) {
+    pcc_set_error("pcc_decode_gop_packed: out of host memory");
+    return PCC_E_NOMEM;
+  } catch (const std::exception& e) {
+    pcc_set_error("pcc_decode_gop_packed: %s", e.what());
+    return PCC_E_STREAM;
+  }
+}
+
+// Point count a container announces: the sum over its frames of the finest of the three k (the decoder keeps at most
+// that many rows per frame).  Host-only parse of the header and the frame slots; nothing is validated beyond their bounds.
+extern "C" int pcc_container_points(const uint8_t* h_in, int64_t len, int64_t* h_n_points, int32_t* h_n_frames) {
+  PCC_REQUIRE(h_in && len >= 36 && h_n_points, PCC_E_STREAM, "pcc_container_points: container shorter than its header");
+  Reader r{h_in, len};
+  const int32_t word0 = r.be32();
+  const int32_t n_frames = (int32_t)((uint32_t)word0 & 0x00FFFFFFu);
+  (void)r.be_f64();
+  (void)r.be_f64();
+  (void)r.be32();
+  (void)r.be32();
+  const int32_t ylen = r.be32(), zlen = r.be32();
+  (void)r.bytes(ylen);
+  (void)r.bytes(zlen);
+  PCC_REQUIRE(!r.bad && n_frames >= 0 && n_frames <= 65535, PCC_E_STREAM, "pcc_container_points: truncated container");
+  int64_t total = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const int32_t pl = r.be32();
+    int32_t k[3];
+    for (int s = 0; s < 3; ++s) k[s] = r.be32();
+    (void)r.bytes(pl);
+    PCC_REQUIRE(!r.bad && k[2] >= 0, PCC_E_STREAM, "pcc_container_points: truncated container");
+    total += k[2];
+  }
+  *h_n_points = total;
+  if (h_n_frames) *h_n_frames = n_frames;
+  return PCC_OK;
 }
 
 // pack_batches (codec_parallel.py:474-502) on the device: xyz without the batch column, colours NaN -> 0 and

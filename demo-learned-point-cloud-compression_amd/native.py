@@ -156,6 +156,8 @@ class NativeCodec:
         return out, ks, dict(zip(ENC_STAGES, ts))
 
     # ------------------------------------------------------------------ decode
+    MAX_ANNOUNCED = 1 << 26   # points: 1.5 GB of destination arrays
+
     def decode(self, data, packed_host=False):
         """container bytes -> (coords int32 [n,4] device, colors float32 [n,3] device, offsets, q, stage seconds).
         The two tensors are copies owned by the caller.  packed_host=True: the cloud as pack_batches returns it, in
@@ -163,6 +165,21 @@ class NativeCodec:
         info = _abi.PccCloudInfo()
         ts = (C.c_double * 6)()
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        if packed_host:
+            # the arrays are sized by what the container announces (an upper bound) and handed to the decoder, which
+            # queues the packing kernel and the transfers behind its last layer: one call, one synchronisation.  A
+            # container that announces more than MAX_ANNOUNCED points is decoded first and its arrays sized afterwards.
+            cap = C.c_int64(0)
+            check(self.lib.pcc_container_points(buf, len(data), C.byref(cap), None), "pcc_container_points")
+            if 0 < cap.value <= self.MAX_ANNOUNCED:
+                pts = np.empty((cap.value, 3), dtype=np.int32)
+                cols = np.empty((cap.value, 3), dtype=np.float32)
+                check(self.lib.pcc_decode_gop_packed(self.handle, buf, len(data), C.c_void_p(pts.ctypes.data),
+                                                     C.c_void_p(cols.ctypes.data), cap.value, C.byref(info), ts),
+                      "pcc_decode_gop_packed")
+                n = int(info.n_points)
+                offsets = [int(info.h_offsets[i]) for i in range(info.n_offsets)]
+                return pts[:n], cols[:n], offsets, [float(info.q_g), float(info.q_a)], dict(zip(DEC_STAGES, ts))
         check(self.lib.pcc_decode_gop(self.handle, buf, len(data), C.byref(info), ts), "pcc_decode_gop")
         n = int(info.n_points)
         offsets = [int(info.h_offsets[i]) for i in range(info.n_offsets)]

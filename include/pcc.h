@@ -581,6 +581,19 @@ int pcc_decode_fetch(pcc_codec* codec, int32_t* d_coords, float* d_colors);
  * clip(c * 255, 0, 255) / 255 applied on the device.  The destinations may be
  * device or host buffers (hipMemcpyDefault); returns when they are filled. */
 int pcc_decode_fetch_packed(pcc_codec* codec, int32_t* points, float* colors);
+/* decompress() into the caller's arrays in one call (codec_parallel.py:141-171 +
+ * pack_batches 474-502): pcc_decode_gop with pcc_decode_fetch_packed's kernel
+ * and transfers queued behind the last layer — no synchronisation and no trip
+ * through the caller between the two.  points / colors hold cap_points rows
+ * (host or device memory); pcc_container_points gives the number of points a
+ * container announces (sum over frames of its finest k, an upper bound of what
+ * is decoded; host-only parse, nothing beyond the slot bounds is validated).
+ * More points decoded than cap_points: PCC_E_ARG, nothing is written. */
+int pcc_container_points(const uint8_t* h_in, int64_t len, int64_t* h_n_points,
+                         int32_t* h_n_frames);
+int pcc_decode_gop_packed(pcc_codec* codec, const uint8_t* h_in, int64_t len,
+                          int32_t* points, float* colors, int64_t cap_points,
+                          pcc_cloud_info* h_info, double* h_stage_s);
 
 /* ---- capture pre-step ------------------------------- */
 

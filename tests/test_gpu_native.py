@@ -159,6 +159,45 @@ def test_native_truncated_container(wl, codec):
     assert c.shape[0] == frames[0]["points"].shape[0]
 
 
+def test_native_decode_into_caller_arrays(wl, codec):
+    """pcc_container_points + pcc_decode_gop_packed: the cloud lands in the caller's host arrays in one call, equal to
+    pcc_decode_gop + pcc_decode_fetch_packed; a destination that is too small is refused and nothing is written;
+    corrupted containers (the announced count included) give a cloud or a PccError, never a write past the arrays"""
+    import ctypes as C
+    native, abi = pkg("native"), pkg("_abi")
+    frames = [wl.sphere_shell(24, 9.1, seed=2), wl.sphere_shell(20, 7.5, seed=4, offset=(30, -9, 4))]
+    coords, feats = _stack(frames)
+    cont, _, _ = codec.encode(coords, feats, 2, [[1, 1]])
+    data = cont[0]
+    n_ref = sum(f["points"].shape[0] for f in frames)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    cap, nf = C.c_int64(0), C.c_int32(0)
+    abi.check(codec.lib.pcc_container_points(buf, len(data), C.byref(cap), C.byref(nf)), "pcc_container_points")
+    assert cap.value == n_ref and nf.value == 2
+    pts, cols, offs, _, _ = codec.decode(data, packed_host=True)          # the one-call form
+    c4, col, offs2, _, _ = codec.decode(data)                               # the two-call form, device tensors
+    assert offs == offs2 and np.array_equal(pts, c4.cpu().numpy()[:, 1:])
+    assert np.array_equal(cols, np.clip(np.nan_to_num(col.cpu().numpy(), nan=0.0) * np.float32(255), 0, 255) / np.float32(255))
+    small_p = np.full((n_ref - 1, 3), -7, np.int32)
+    small_c = np.full((n_ref - 1, 3), -7, np.float32)
+    info, ts = abi.PccCloudInfo(), (C.c_double * 6)()
+    rc = codec.lib.pcc_decode_gop_packed(codec.handle, buf, len(data), C.c_void_p(small_p.ctypes.data),
+                                         C.c_void_p(small_c.ctypes.data), n_ref - 1, C.byref(info), ts)
+    assert rc == -1 and (small_p == -7).all() and (small_c == -7).all()
+    rng = np.random.default_rng(99)
+    for _ in range(30):
+        b = bytearray(data)
+        pos = int(rng.integers(0, len(b)))
+        b[pos] ^= int(rng.integers(1, 256))
+        try:
+            p2, c2, o2, _, _ = codec.decode(bytes(b), packed_host=True)
+            assert p2.shape == c2.shape and o2[-1] == p2.shape[0]
+        except native.PccError as e:
+            assert e.code < 0
+    p3, _, _, _, _ = codec.decode(data, packed_host=True)                   # still usable
+    assert np.array_equal(p3, pts)
+
+
 def test_native_edge_gops(wl, oracle, codec):
     """ragged GOP through pcc_encode_gop / pcc_decode_gop: a one-voxel frame, frames at the int16 corners of the
     coordinate range, ten frames, and a middle frame that prunes to nothing at the coarse levels"""
