@@ -16,7 +16,7 @@ import torch
 
 from . import runtime as _rt
 from . import utils
-from .model import ColorModel
+from .model import ColorModel, load_model_dir
 from .native import NativeCodec
 from .sparse import SparseTensor
 
@@ -50,7 +50,8 @@ class DecompressionPipeline:
 
     def load_model(self, base_path):
         model_name = "demo_small"
-        decompression_model = ColorModel({"name": model_name})
+        config, tensors = load_model_dir(base_path, model_name)
+        decompression_model = ColorModel(config, tensors)
         decompression_model.load_state_dict(None)
         decompression_model.to(self.device)
         decompression_model.update()

@@ -29,7 +29,7 @@ import torch
 
 from . import runtime as _rt
 from . import utils
-from .model import ColorModel
+from .model import ColorModel, load_model_dir
 from .native import NativeCodec
 from .sparse import SparseTensor
 
@@ -71,7 +71,7 @@ class CompressionPipeline:
         # back to back like the reference's asynchronous torch ops and only data hand-overs wait
         self.stage_sync = (os.environ.get("PCC_STAGE_SYNC", "0") == "1") if stage_sync is None else bool(stage_sync)
         self.settings = [[float(q[0]), float(q[1])] for q in settings]
-        base_path = "./unified/results/"          # kept for signature parity; the checkpoint ships in-tree
+        base_path = "./unified/results/"          # as the reference; without that directory the in-tree checkpoint is used
         self.compression_model = self.load_model(base_path)
         self._slots = queue.Queue()
         if self.engine == "native":
@@ -101,7 +101,8 @@ class CompressionPipeline:
 
     def load_model(self, base_path):
         model_name = "demo_small"
-        compression_model = ColorModel({"name": model_name})
+        config, tensors = load_model_dir(base_path, model_name)
+        compression_model = ColorModel(config, tensors)
         compression_model.load_state_dict(None)
         compression_model.to(self.device)
         compression_model.update()

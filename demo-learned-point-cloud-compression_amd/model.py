@@ -32,6 +32,36 @@ def load_checkpoint(name="demo_small"):
         return {k: f[k] for k in f.files}
 
 
+def load_model_dir(base_path, model_name):
+    """What the reference's load_model(base_path) reads (sender/encoder/codec_pipeline.py:56-72): the directory
+    <base_path>/<model_name>/ with config.yaml and the weights.  Returns (config["model"], tensors).
+      * weights.npz there (this build's checkpoint format: the tensor names of tools/make_checkpoint.py, CDF tables
+        included) is loaded; config.yaml, when present, supplies the model section;
+      * only weights.pt there — a torch state_dict of the reference's model package, which is not in its tree, so its
+        key names, MinkowskiEngine kernel layouts and CompressAI table builders cannot be restated here: refused with
+        that message rather than silently replaced;
+      * no such directory: the seeded in-tree checkpoint (assets/<model_name>.npz)."""
+    d = os.path.join(base_path or "", model_name)
+    config = {"name": model_name}
+    cfg = os.path.join(d, "config.yaml")
+    if os.path.isfile(cfg):
+        import yaml
+        with open(cfg, "r") as f:
+            loaded = yaml.safe_load(f) or {}
+        config = dict(loaded.get("model", {}) or {})
+        config.setdefault("name", model_name)
+    npz = os.path.join(d, "weights.npz")
+    if os.path.isfile(npz):
+        with np.load(npz) as f:
+            return config, {k: f[k] for k in f.files}
+    if os.path.isfile(os.path.join(d, "weights.pt")):
+        raise FileNotFoundError(
+            f"{d}: weights.pt is a state_dict of the reference's model package (unified.model), which is not part of "
+            f"its tree: this build cannot map its keys.  Export the tensors under the names of tools/make_checkpoint.py "
+            f"to {npz} (numpy .npz) and it is loaded from there.")
+    return config, load_checkpoint(model_name)
+
+
 class _Params:
     """device-resident weights, one copy per device"""
 
@@ -192,9 +222,9 @@ class EntropyModel:
 
 
 class ColorModel:
-    def __init__(self, config=None):
+    def __init__(self, config=None, tensors=None):
         self.config = config or {"name": "demo_small"}
-        self.tensors = load_checkpoint(self.config.get("name", "demo_small"))
+        self.tensors = tensors if tensors is not None else load_checkpoint(self.config.get("name", "demo_small"))
         self.device = None
         self.params = None
         self.g_a = self.g_s = self.entropy_model = None
