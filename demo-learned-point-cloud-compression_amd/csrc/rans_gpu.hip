@@ -21,6 +21,14 @@
 // per chunk, four chunks per workgroup; the CDF rows (27k entries for the 64 Gaussian tables) live in LDS as uint16
 // and a symbol is found by binary search there.  All integer: bit-exact against oracle/pcc_oracle.c
 // (orc_rans_interleaved_*), which restates the same order sequentially.
+//
+// Time: a launch lasts as long as ONE chunk — T sequential steps of one wave alone on its SIMD, ~0.66 us each: 150-200
+// dependent instructions (64-bit integer arithmetic in 32-bit pieces, ballots, the f64 reciprocal product) at the ~8
+// cycles a lone wave gets per dependent instruction.  What is NOT on that chain any more: the symbol / index loads (eight
+// steps in flight), the encoder's table lookups and 1 / freq (done one step ahead), the decoder's stream words (128 of
+// them in two registers per lane, refilled 64 words before they are needed).  Measured and dropped: 256 buckets with a
+// four-entry resolve instead of 64 buckets + binary search in the decoder (two dependent LDS reads instead of four to
+// five: 0.36 -> 0.42 ms, more instructions).  Shorter chunks buy time with rate (512 B of final states per chunk).
 #include "common.h"
 
 #include <string.h>
@@ -191,37 +199,61 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
       rv = sidx ? (int)sidx[i] : (int)(i / idx_run);
     }
   };
-  int32_t sv_n;
-  int rv_n;
-  fetch(T - 1, sv_n, rv_n);
-  for (int64_t t = T - 1; t >= 0; --t) {
+  // kEncAhead steps of symbols and table indexes are in flight: a step's own arithmetic is a few hundred cycles, a
+  // load that misses L2 takes longer than that, and with one step of distance the step time WAS the memory latency.
+  // The table work of a step — row, bin, escape nibbles, 1 / freq — does not depend on the coder state either: it is
+  // done one step ahead (prep), so that the chain from state to state is the renormalisation ballot, one multiply by the
+  // reciprocal and the remainder correction, with no LDS round trip and no division on it.
+  constexpr int kEncAhead = 8;
+  int32_t sv_q[kEncAhead];
+  int rv_q[kEncAhead];
+#pragma unroll
+  for (int d = 0; d < kEncAhead; ++d) fetch(T - 1 - d, sv_q[d], rv_q[d]);
+  struct Prep {
+    int32_t start, freq, nb;
+    uint32_t raw;
+    bool esc, act;
+    double rinv;
+  };
+  auto prep = [&](int64_t t, int32_t sv, int r) -> Prep {
+    Prep p{0, 1, 0, 0u, false, false, 1.0};
     const int64_t i = base + t * kLanes + lane;
-    const bool act = i < n;
-    const int32_t sv = sv_n;
-    const int r = rv_n;
-    fetch(t - 1, sv_n, rv_n);
-    int32_t start = 0, freq = 1, nb = 0;
-    uint32_t raw = 0;
-    bool esc = false;
-    if (act) {
+    p.act = t >= 0 && i < n;
+    if (p.act) {
       const int off = s_row[3 * r], len = s_row[3 * r + 1];
       const int32_t max_value = len - 2;
       int32_t v = sv - s_row[3 * r + 2];
       if (v < 0) {
-        raw = (uint32_t)(-2 * (int64_t)v - 1);
+        p.raw = (uint32_t)(-2 * (int64_t)v - 1);
         v = max_value;
       } else if (v >= max_value) {
-        raw = (uint32_t)(2 * ((int64_t)v - max_value));
+        p.raw = (uint32_t)(2 * ((int64_t)v - max_value));
         v = max_value;
       }
-      esc = v == max_value;
-      if (esc)
-        while (nb < 8 && (raw >> (4 * nb)) != 0) ++nb;
+      p.esc = v == max_value;
+      if (p.esc)
+        while (p.nb < 8 && (p.raw >> (4 * p.nb)) != 0) ++p.nb;
       const uint32_t c0 = s_cdf[off + v], c1 = s_cdf[off + v + 1];
-      start = (int32_t)c0;
-      freq = (int32_t)((c1 - c0) & 0xFFFFu);
-      if (freq == 0) freq = 65536;
+      p.start = (int32_t)c0;
+      p.freq = (int32_t)((c1 - c0) & 0xFFFFu);
+      if (p.freq == 0) p.freq = 65536;
+      p.rinv = 1.0 / (double)p.freq;
     }
+    return p;
+  };
+  Prep cur = prep(T - 1, sv_q[0], rv_q[0]);
+  for (int64_t t0 = T - 1; t0 >= 0; t0 -= kEncAhead) {
+#pragma unroll
+   for (int d = 0; d < kEncAhead; ++d) {
+    const int64_t t = t0 - d;
+    if (t < 0) break;   // wave-uniform
+    // the queue slot of step t is free (prep(t) consumed it a step ago): request step t - kEncAhead into it, then
+    // prepare step t - 1 from the slot behind it
+    fetch(t - kEncAhead, sv_q[d], rv_q[d]);
+    const Prep nxt = prep(t - 1, sv_q[(d + 1) % kEncAhead], rv_q[(d + 1) % kEncAhead]);
+    const bool act = cur.act, esc = cur.esc;
+    const int32_t start = cur.start, freq = cur.freq, nb = cur.nb;
+    const uint32_t raw = cur.raw;
     // bypass rounds of the escaped lanes, last round first: round 1 = nibble count, round 2 + j = nibble j
     if (__ballot(esc) != 0ull) {
       for (int r = 9; r >= 1; --r) {
@@ -257,16 +289,19 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
       }
       if (need) x >>= 32;
       if (act) {
-        // x / freq, x % freq with x < 2^47 freq: the quotient from one double division (exact to within one, the 53-bit
-        // mantissa holds any quotient below 2^47), corrected by the remainder — instead of the 64-bit division routine
+        // x / freq, x % freq with x < 2^47 freq: the quotient from one multiplication by 1 / freq in double (x and the
+        // reciprocal are each within 2^-52 of exact and the quotient is below 2^47: off by at most one), corrected by
+        // the remainder — no division routine and no division on the chain from state to state
         const uint64_t f = (uint32_t)freq;
-        uint64_t qd = (uint64_t)((double)x / (double)f);
+        uint64_t qd = (uint64_t)((double)x * cur.rinv);
         int64_t rem = (int64_t)(x - qd * f);
         if (rem < 0) { --qd; rem += (int64_t)f; }
         else if (rem >= (int64_t)f) { ++qd; rem -= (int64_t)f; }
         x = (qd << 16) + (uint64_t)rem + (uint32_t)start;
       }
     }
+    cur = nxt;
+   }
   }
   if (!overflow) {
     ptr -= 2 * kLanes;
@@ -357,16 +392,21 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   int64_t ptr = 2 * kLanes;
   const int64_t base = c * kLanes * T;
 
-  // The next 64 words of the chunk are requested as soon as the read position is known (one coalesced load per step),
-  // so a lane that renormalises takes its word from a register of another lane (ds_bpermute) instead of waiting for a
-  // load that depends on the state it has just computed.
+  // The words of the chunk are held 128 at a time in two registers per lane — A = words [wb, wb + 64), B = the 64 behind
+  // them, wb a multiple of 64 with wb <= ptr < wb + 64 — so a lane that renormalises takes its word from a register of
+  // another lane (ds_bpermute), and the load that refills B is requested when the read position crosses into it: at
+  // least 64 words, several steps, before its first word is needed.  (With ONE window reloaded at every new read
+  // position, each step waited for a load it had just issued: the step time was the memory latency.)
   auto window = [&](int64_t at) -> uint32_t { return at + lane < (int64_t)cw ? p[at + lane] : 0u; };
-  uint32_t win = window(ptr);
+  int64_t wb = ptr & ~(int64_t)63;
+  uint32_t win_a = window(wb), win_b = window(wb + 64);
   auto refill = [&](bool need) {
     const unsigned long long bal = __ballot(need);
     const int cnt = __popcll(bal);
     if (cnt) {
-      const uint32_t w = (uint32_t)__shfl((int)win, lane_rank(bal), 64);
+      const int at = (int)(ptr - wb) + lane_rank(bal);   // 0 .. 126
+      const uint32_t wa = (uint32_t)__shfl((int)win_a, at & 63, 64), wbv = (uint32_t)__shfl((int)win_b, at & 63, 64);
+      const uint32_t w = at < 64 ? wa : wbv;
       if (ptr + cnt > (int64_t)cw) {
         bad |= 1;
         if (need) x = kL;   // keep the arithmetic defined; the status word reports the stream
@@ -374,21 +414,33 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
         if (need) x = (x << 32) | w;
         ptr += cnt;
       }
-      win = window(ptr);
+      if (ptr - wb >= 64) {   // wave-uniform
+        wb += 64;
+        win_a = win_b;
+        win_b = window(wb + 64);
+      }
     }
   };
+  // table indexes: kDecAhead steps in flight
+  constexpr int kDecAhead = 8;
   auto fetch_idx = [&](int64_t t) -> int {
     const int64_t i = base + t * kLanes + lane;
     if (t >= T || i >= n) return 0;
     return idx ? (int)idx[i] : (int)(i / idx_run);
   };
-  int r_n = fetch_idx(0);
+  int r_q[kDecAhead];
+#pragma unroll
+  for (int d = 0; d < kDecAhead; ++d) r_q[d] = fetch_idx(d);
 
-  for (int64_t t = 0; t < T; ++t) {
+  for (int64_t t0 = 0; t0 < T; t0 += kDecAhead) {
+#pragma unroll
+   for (int d = 0; d < kDecAhead; ++d) {
+    const int64_t t = t0 + d;
+    if (t >= T) break;   // wave-uniform
     const int64_t i = base + t * kLanes + lane;
     const bool act = i < n;
-    const int r = r_n;
-    r_n = fetch_idx(t + 1);
+    const int r = r_q[d];
+    r_q[d] = fetch_idx(t + kDecAhead);
     int32_t value = 0, max_value = 0, off_sym = 0;
     bool esc = false;
     if (act) {
@@ -442,6 +494,7 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
       }
     }
     if (act) sym[i] = value + off_sym;
+   }
   }
   const unsigned long long b1 = __ballot((bad & 1) != 0), b2 = __ballot((bad & 2) != 0);
   if (lane == 0 && (b1 | b2) != 0ull) atomicOr(status, (b1 ? 1 : 0) | (b2 ? 2 : 0));
