@@ -15,6 +15,7 @@ same way, `assemble_tiles` undoes the round-robin deal and `merge_tiles` joins t
 into the scan.  Without a process group (world size 1) the same functions run all tiles
 in this process and no collective is issued.
 """
+import os
 import struct
 
 import numpy as np
@@ -113,7 +114,9 @@ def all_gather_bytes(local, device, group=None):
     """every rank contributes one byte string; returns the list of all ranks' strings
     (identical on every rank).  Two collectives: lengths, then padded payloads."""
     world = _world(group)
-    if world == 1:
+    # (PCC_TILED_FORCE_COLLECTIVE=1: a world of one rank still goes through the two collectives — how bench.py's
+    # PCC_BENCH_TILED=1 rehearsal exercises them over RCCL on a one-GPU box)
+    if world == 1 and not (os.environ.get("PCC_TILED_FORCE_COLLECTIVE") == "1" and dist.is_available() and dist.is_initialized()):
         return [bytes(local)]
     n = torch.tensor([len(local)], dtype=torch.int64, device=device)
     lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
