@@ -155,6 +155,11 @@ def host_cpu_budget():
             break
         except (OSError, ValueError, IndexError):
             continue
+    # one process per GPU (torch.distributed.run): the ranks of a node share its cores and, usually, one cgroup
+    try:
+        n //= max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        pass
     return max(1, n)
 
 
