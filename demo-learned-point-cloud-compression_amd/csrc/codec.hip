@@ -453,9 +453,15 @@ struct View {
 
 int view_of(pcc_codec* cd, CS* s, View* v) {
   const int64_t cap = std::max<int64_t>(s->n, 1);
-  CODEC_ALLOC(c, int32_t, 4 * cap);
   CODEC_ALLOC(perm, uint32_t, cap);
   CODEC_ALLOC(cs, int32_t, 4 * cap);
+  if (s->n > 0 && s->n <= pcc_sort_small_max()) {
+    // latent-sized set: order and ordered rows straight from the keys
+    PCC_TRY(pcc_sort_keys_canonical(cd->ctx, s->keys, s->n, perm, cs));
+    *v = {cs, perm, s->n};
+    return PCC_OK;
+  }
+  CODEC_ALLOC(c, int32_t, 4 * cap);
   if (s->n > 0) {
     PCC_TRY(pcc_keys_to_coords(cd->ctx, s->keys, s->n, c));
     PCC_TRY(pcc_sort_coords(cd->ctx, c, s->n, perm));

@@ -81,6 +81,9 @@ bool pcc_conv_up_fused();
 // conv.hip: frees the operand-ordered weight copies of a context (pcc_destroy)
 void pcc_wcache_free(pcc_ctx* ctx);
 // conv.hip: pcc_sparse_conv_head_up on input rows whose 32 channels are stored in the order kConv16Perm below
+// sort.hip: canonical order + rows in that order of a small coordinate set given by its Morton keys
+int64_t pcc_sort_small_max();
+int pcc_sort_keys_canonical(pcc_ctx* ctx, const uint64_t* d_mkeys, int64_t n, uint32_t* d_perm, int32_t* d_sorted_coords);
 // octree.hip: the single-workgroup octree kernel without any read-back (codec.hip's geometry slot)
 int pcc_octree_small_max();
 int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,

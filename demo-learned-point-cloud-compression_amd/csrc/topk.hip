@@ -90,15 +90,25 @@ __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ log
   __syncthreads();
   const int shift = 24 - 8 * pass;
   const uint32_t himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
-  for (int64_t r = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; r < hi; r += (int64_t)gridDim.x * 256) {
-    uint32_t k;
-    if (pass == 0) {
-      k = ordered_key(logits[r]);
-      keys[r] = k;
-    } else {
-      k = keys[r];
+  // four independent loads in flight per thread: with one, a thread's dozen iterations each paid a full memory
+  // latency in front of their LDS atomic (23-26 us for 3.26M keys, a 13-MB read)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t r0 = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; r0 < hi; r0 += 4 * stride) {
+    uint32_t k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + u * stride;
+      k[u] = 0u;
+      if (r < hi) k[u] = pass == 0 ? ordered_key(logits[r]) : keys[r];
     }
-    if (((k ^ s.prefix) & himask) == 0u) atomicAdd(&lh[(k >> shift) & 255u], 1u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + u * stride;
+      if (r < hi) {
+        if (pass == 0) keys[r] = k[u];
+        if (((k[u] ^ s.prefix) & himask) == 0u) atomicAdd(&lh[(k[u] >> shift) & 255u], 1u);
+      }
+    }
   }
   __syncthreads();
   const uint32_t c = lh[threadIdx.x];
