@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void k_build_map27(
 
 // The coarsest levels of a pyramid are a few thousand rows (the z level of the bench frame: 1594): hash fill + insert +
 // probe rounds are three launches of pure latency for them.  Here every workgroup copies the whole (Morton-sorted) key
-// array into LDS and each thread finds the 26 neighbours of its row by binary search there — one launch.
+// array into LDS and a thread finds ONE neighbour of one row by binary search there (row = thread / 27... laid out
+// offset-major: workgroup (bx, k) serves offset k of rows 256 bx ..) — one launch, a dozen dependent LDS reads per
+// thread.  (With the 26 searches of a row in one thread, advancing together, the launch took 28 us at ~170 registers.)
 #define MAP_SMALL_MAX 4096
 __global__ __launch_bounds__(256) void k_build_map27_small(const uint64_t* __restrict__ keys, int n, int stride,
                                                            int32_t* __restrict__ nbr) {
@@ -145,43 +147,28 @@ __global__ __launch_bounds__(256) void k_build_map27_small(const uint64_t* __res
   for (int e = threadIdx.x; e < n; e += 256) sk[e] = keys[e];
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
   if (i >= n) return;
-  int b, x, y, z;
-  pcc_unmorton(sk[i], &b, &x, &y, &z);
-  const uint64_t bk = (uint64_t)(uint32_t)b << 48;
-  // the 26 searches advance together, one LDS read each per step: their latencies overlap instead of adding up
-  uint64_t q[27];
-  int lo[27], hi[27];
-  uint32_t okm = 0;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
+  int32_t r = -1;
+  if (k == 13) {
+    r = i;
+  } else {
+    int b, x, y, z;
+    pcc_unmorton(sk[i], &b, &x, &y, &z);
     const int nx = x + (k / 9 - 1) * stride, ny = y + ((k / 3) % 3 - 1) * stride, nz = z + (k % 3 - 1) * stride;
-    const bool ok = k != 13 && nx >= -32768 && nx <= 32767 && ny >= -32768 && ny <= 32767 && nz >= -32768 && nz <= 32767;
-    okm |= (ok ? 1u : 0u) << k;
-    q[k] = bk | (pcc_spread3((uint32_t)(nx + 32768)) << 2) | (pcc_spread3((uint32_t)(ny + 32768)) << 1) |
-           pcc_spread3((uint32_t)(nz + 32768));
-    lo[k] = 0;
-    hi[k] = ok ? n : 0;  // an empty range finds nothing
-  }
-  int steps = 0;
-  while ((1 << steps) <= n) ++steps;  // enough halvings to empty a range of n (uniform)
-  for (int s = 0; s < steps; ++s) {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      const int mid = (lo[k] + hi[k]) >> 1;
-      const uint64_t v = sk[min(mid, n - 1)];
-      const bool go = lo[k] < hi[k];
-      if (go && v < q[k]) lo[k] = mid + 1;
-      else if (go) hi[k] = mid;
+    if (nx >= -32768 && nx <= 32767 && ny >= -32768 && ny <= 32767 && nz >= -32768 && nz <= 32767) {
+      const uint64_t q = ((uint64_t)(uint32_t)b << 48) | (pcc_spread3((uint32_t)(nx + 32768)) << 2) |
+                         (pcc_spread3((uint32_t)(ny + 32768)) << 1) | pcc_spread3((uint32_t)(nz + 32768));
+      int lo = 0, hi = n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sk[mid] < q) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < n && sk[lo] == q) r = lo;
     }
   }
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    int32_t r = -1;
-    if (k == 13) r = i;
-    else if (((okm >> k) & 1u) && lo[k] < n && sk[lo[k]] == q[k]) r = lo[k];
-    nbr[(int64_t)k * n + i] = r;
-  }
+  nbr[(int64_t)k * n + i] = r;
 }
 
 __global__ void k_lookup(const uint64_t* __restrict__ qkeys, int64_t m,
@@ -389,6 +376,38 @@ static int build_table(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, unsigned
   return PCC_OK;
 }
 
+// Latent-sized levels (a few thousand to a few ten thousand rows): one thread per (row, offset) instead of 27 batched
+// probes per row — 27 times the threads for a launch that was a handful of workgroups waiting on 27-deep register
+// arrays (34 us for 26k rows); grid.y = offset, so a workgroup's stores are one coalesced run of its offset's row.
+__global__ __launch_bounds__(256) void k_build_map27_each(const uint64_t* __restrict__ keys, int n, int stride,
+                                                          const unsigned long long* __restrict__ tk,
+                                                          const uint32_t* __restrict__ tv, uint64_t mask,
+                                                          int32_t* __restrict__ nbr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= n) return;
+  int32_t r = -1;
+  if (k == 13) {
+    r = i;
+  } else {
+    int b, x, y, z;
+    pcc_unmorton(keys[i], &b, &x, &y, &z);
+    const int nx = x + (k / 9 - 1) * stride, ny = y + ((k / 3) % 3 - 1) * stride, nz = z + (k % 3 - 1) * stride;
+    if (nx >= -32768 && nx <= 32767 && ny >= -32768 && ny <= 32767 && nz >= -32768 && nz <= 32767) {
+      const uint64_t q = ((uint64_t)(uint32_t)b << 48) | (pcc_spread3((uint32_t)(nx + 32768)) << 2) |
+                         (pcc_spread3((uint32_t)(ny + 32768)) << 1) | pcc_spread3((uint32_t)(nz + 32768));
+      uint32_t slot = (uint32_t)(hash64(q) & mask);
+      for (uint64_t step = 0; step <= mask; ++step) {
+        const unsigned long long got = tk[slot];
+        if (got == q) { r = (int32_t)tv[slot]; break; }
+        if (got == HASH_EMPTY) break;
+        slot = (slot + 1) & (uint32_t)mask;
+      }
+    }
+  }
+  nbr[(int64_t)k * n + i] = r;
+}
+
 extern "C" int pcc_build_map(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int stride,
                              int32_t* d_nbr) {
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_build_map: null ctx");
@@ -399,7 +418,7 @@ extern "C" int pcc_build_map(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, in
   PCC_REQUIRE(n < ((int64_t)1 << 30), PCC_E_ARG, "pcc_build_map: n too large");
   PccProfScope prof(ctx, "build_map", n, stride, 0, 27);
   if (n <= MAP_SMALL_MAX) {  // keys are Morton-sorted (every coordinate set of the path is): binary search in LDS
-    hipLaunchKernelGGL(k_build_map27_small, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_keys, (int)n, stride,
+    hipLaunchKernelGGL(k_build_map27_small, dim3(nblk(n, 256), 27), dim3(256), 0, ctx->stream, d_keys, (int)n, stride,
                        d_nbr);
     PCC_CHECK_LAUNCH();
     return PCC_OK;
@@ -410,8 +429,12 @@ extern "C" int pcc_build_map(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, in
   uint32_t* tv;
   uint64_t mask;
   PCC_TRY(build_table(ctx, d_keys, n, &tk, &tv, &mask));
-  hipLaunchKernelGGL(k_build_map27, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_keys, n,
-                     stride, (const unsigned long long*)tk, (const uint32_t*)tv, mask, d_nbr);
+  if (n <= 65536)
+    hipLaunchKernelGGL(k_build_map27_each, dim3(nblk(n, 256), 27), dim3(256), 0, ctx->stream, d_keys, (int)n, stride,
+                       (const unsigned long long*)tk, (const uint32_t*)tv, mask, d_nbr);
+  else
+    hipLaunchKernelGGL(k_build_map27, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_keys, n,
+                       stride, (const unsigned long long*)tk, (const uint32_t*)tv, mask, d_nbr);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -180,10 +180,10 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
                                                            uint64_t* __restrict__ tmp_k,
                                                            uint32_t* __restrict__ tmp_v, int n, uint64_t flip,
                                                            const int* __restrict__ done /*nullable*/,
-                                                           const uint64_t* __restrict__ mkeys = nullptr,
+                                                           const int4* __restrict__ rows_in = nullptr,
                                                            int4* __restrict__ sorted_out = nullptr) {
-  // mkeys / sorted_out (both or neither): the rows behind the sorted keys are Morton keys of coordinates; written out
-  // in sorted order at the end (pcc_sort_keys_canonical)
+  // rows_in / sorted_out (both or neither): the rows behind the sorted keys, written out in sorted order at the end
+  // (pcc_sort_keys_canonical)
   if (done && *done) return;  // k_compact_coord_keys already wrote the permutation (block-uniform)
   __shared__ uint32_t cnt[SS_WAVES][256];
   __shared__ unsigned long long s_or, s_and;
@@ -235,11 +235,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
     if (all_ok) {
       for (int e = tid; e < n; e += SS_THREADS) {
         perm[e] = (uint32_t)e;
-        if (sorted_out) {
-          int b, x, y, z;
-          pcc_unmorton(mkeys[e], &b, &x, &y, &z);
-          sorted_out[e] = make_int4(b, x, y, z);
-        }
+        if (sorted_out) sorted_out[e] = rows_in[e];
       }
       return;
     }
@@ -334,18 +330,13 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
     if (kin != keys) for (int e = tid; e < n; e += SS_THREADS) keys[e] = kin[e];
     if (vin != perm) for (int e = tid; e < n; e += SS_THREADS) perm[e] = vin[e];
   }
-  if (sorted_out) {
-    for (int e = tid; e < n; e += SS_THREADS) {
-      int b, x, y, z;
-      pcc_unmorton(mkeys[vin ? vin[e] : (uint32_t)e], &b, &x, &y, &z);
-      sorted_out[e] = make_int4(b, x, y, z);
-    }
-  }
+  if (sorted_out)
+    for (int e = tid; e < n; e += SS_THREADS) sorted_out[e] = rows_in[vin ? vin[e] : (uint32_t)e];
 }
 
 // Sort with scratch already reserved in the arena.
 static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
-                           int is_signed, const int* d_done = nullptr, const uint64_t* d_mkeys = nullptr,
+                           int is_signed, const int* d_done = nullptr, const int4* d_rows = nullptr,
                            int4* d_sorted = nullptr) {
   hipStream_t st = ctx->stream;
   if (n <= 0) return PCC_OK;
@@ -360,7 +351,7 @@ static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int
   if (n <= SS_MAX) {
     if (!tmp_k || !tmp_v) return PCC_E_NOMEM;
     hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, st, d_keys, d_perm, tmp_k, tmp_v, (int)n,
-                       is_signed ? (1ull << 63) : 0ull, d_done, d_mkeys, d_sorted);
+                       is_signed ? (1ull << 63) : 0ull, d_done, d_rows, d_sorted);
     PCC_CHECK_LAUNCH();
     return PCC_OK;
   }
@@ -523,26 +514,9 @@ extern "C" int pcc_sort_pairs(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, 
 #define CK_BITMAP_BITS 20
 #define CK_U 8
 
-// FROM_KEYS: the rows are given as Morton keys (a coordinate set's own form) and decoded on the fly, and the rows in
-// canonical order are written as well (sorted_out[rank] = row): one launch instead of keys -> coordinates, this
-// kernel, and a gather of the coordinates by the permutation (codec.hip view_of, four times per GOP).
-struct CoordSource {
-  const int4* coords;
-  const uint64_t* mkeys;
-};
-template <bool FROM_KEYS>
-__device__ __forceinline__ int4 ck_row(const CoordSource& src, int e) {
-  if constexpr (FROM_KEYS) {
-    int b, x, y, z;
-    pcc_unmorton(src.mkeys[e], &b, &x, &y, &z);
-    return make_int4(b, x, y, z);
-  } else {
-    return src.coords[e];
-  }
-}
-
-template <bool FROM_KEYS>
-__global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(CoordSource src, int n,
+// sorted_out (nullable): the rows in canonical order are written as well (sorted_out[rank] = row), which saves the
+// gather of the coordinates by the permutation behind this kernel (codec.hip view_of, four times per GOP).
+__global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(const int4* __restrict__ coords, int n,
                                                                    uint64_t* __restrict__ keys,
                                                                    uint32_t* __restrict__ perm,
                                                                    int* __restrict__ done,
@@ -557,7 +531,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(CoordSource s
   __syncthreads();
   // one sweep: min / max per field, range check, and the bits in which rows differ from row 0 (the lowest such
   // bit is the lowest set bit of OR(c - min): both say "all rows are congruent mod 2^tz")
-  const int4 c0 = ck_row<FROM_KEYS>(src, 0);
+  const int4 c0 = coords[0];
   int mn[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
   int mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   unsigned orv[4] = {0u, 0u, 0u, 0u};
@@ -565,7 +539,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(CoordSource s
   for (int e0 = tid; e0 < n; e0 += CK_U * SS_THREADS) {
     int4 cc[CK_U];  // CK_U independent loads in flight per lane (clamped index: duplicates do not change min / max / or)
 #pragma unroll
-    for (int u = 0; u < CK_U; ++u) cc[u] = ck_row<FROM_KEYS>(src, min(e0 + u * SS_THREADS, n - 1));
+    for (int u = 0; u < CK_U; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
 #pragma unroll
     for (int u = 0; u < CK_U; ++u) {
       const int4 c = cc[u];
@@ -628,7 +602,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(CoordSource s
     for (int e0 = tid; e0 < n; e0 += CK_U * SS_THREADS) {
       int4 cc[CK_U];
 #pragma unroll
-      for (int u = 0; u < CK_U; ++u) cc[u] = ck_row<FROM_KEYS>(src, min(e0 + u * SS_THREADS, n - 1));
+      for (int u = 0; u < CK_U; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
 #pragma unroll
       for (int u = 0; u < CK_U; ++u) {
         if (e0 + u * SS_THREADS < n) {
@@ -660,7 +634,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(CoordSource s
       for (int e0 = tid; e0 < n; e0 += CK_U * SS_THREADS) {
         int4 cc[CK_U];
 #pragma unroll
-        for (int u = 0; u < CK_U; ++u) cc[u] = ck_row<FROM_KEYS>(src, min(e0 + u * SS_THREADS, n - 1));
+        for (int u = 0; u < CK_U; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
 #pragma unroll
         for (int u = 0; u < CK_U; ++u) {
           const int e = e0 + u * SS_THREADS;
@@ -683,7 +657,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(CoordSource s
   for (int e0 = tid; e0 < n; e0 += CK_U * SS_THREADS) {
     int4 cc[CK_U];
 #pragma unroll
-    for (int u = 0; u < CK_U; ++u) cc[u] = ck_row<FROM_KEYS>(src, min(e0 + u * SS_THREADS, n - 1));
+    for (int u = 0; u < CK_U; ++u) cc[u] = coords[min(e0 + u * SS_THREADS, n - 1)];
 #pragma unroll
     for (int u = 0; u < CK_U; ++u) {
       const int e = e0 + u * SS_THREADS;
@@ -712,8 +686,8 @@ extern "C" int pcc_sort_coords(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
   if (!lk || !done) return PCC_E_NOMEM;
   PccProfScope prof(ctx, "sort_coords", n, 0, 0, 0);
   if (n <= SS_MAX) {
-    hipLaunchKernelGGL(k_compact_coord_keys<false>, dim3(1), dim3(SS_THREADS), 0, ctx->stream,
-                       CoordSource{(const int4*)d_coords, nullptr}, (int)n, (uint64_t*)lk, d_perm, done, (int4*)nullptr);
+    hipLaunchKernelGGL(k_compact_coord_keys, dim3(1), dim3(SS_THREADS), 0, ctx->stream, (const int4*)d_coords, (int)n,
+                       (uint64_t*)lk, d_perm, done, (int4*)nullptr);
     PCC_CHECK_LAUNCH();
     return sort_pairs_impl(ctx, (uint64_t*)lk, d_perm, n, 0, done);
   }
@@ -724,22 +698,25 @@ extern "C" int pcc_sort_coords(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
 }
 
 // Internal (codec.hip view_of): canonical order of a coordinate set given by its Morton keys — the permutation AND the
-// rows [n,4] (b,x,y,z) in that order, for sets within the single-workgroup kernels (n <= pcc_sort_small_max()): two
-// launches (the second returns at once when the first has done the work) instead of keys -> coordinates, the order,
-// and a gather.
+// rows [n,4] (b,x,y,z) in that order, for sets within the single-workgroup kernels (n <= pcc_sort_small_max()): the
+// keys are turned into coordinates by a plain parallel kernel (inside the one-workgroup kernel, which sweeps the rows
+// three times, the bit de-interleaving cost 28 us for 26k rows), the order kernel writes the ordered rows itself.
 int64_t pcc_sort_small_max() { return SS_MAX; }
 int pcc_sort_keys_canonical(pcc_ctx* ctx, const uint64_t* d_mkeys, int64_t n, uint32_t* d_perm, int32_t* d_sorted_coords) {
   PCC_REQUIRE(ctx && d_mkeys && d_perm && d_sorted_coords && n >= 1 && n <= SS_MAX, PCC_E_ARG,
               "pcc_sort_keys_canonical: bad argument (n=%lld)", (long long)n);
-  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n) + pcc_align((size_t)n * 8) + 256));
+  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n) + pcc_align((size_t)n * 8) + pcc_align((size_t)n * 16) + 256));
   int64_t* lk = (int64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
+  int4* c = (int4*)pcc_arena_alloc(ctx, (size_t)n * 16);
   int* done = (int*)pcc_arena_alloc(ctx, 4);
-  if (!lk || !done) return PCC_E_NOMEM;
+  if (!lk || !c || !done) return PCC_E_NOMEM;
   PccProfScope prof(ctx, "sort_coords", n, 0, 0, 0);
-  hipLaunchKernelGGL(k_compact_coord_keys<true>, dim3(1), dim3(SS_THREADS), 0, ctx->stream, CoordSource{nullptr, d_mkeys},
-                     (int)n, (uint64_t*)lk, d_perm, done, (int4*)d_sorted_coords);
+  hipLaunchKernelGGL(k_keys_to_coords, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_mkeys, n, c);
   PCC_CHECK_LAUNCH();
-  return sort_pairs_impl(ctx, (uint64_t*)lk, d_perm, n, 0, done, d_mkeys, (int4*)d_sorted_coords);
+  hipLaunchKernelGGL(k_compact_coord_keys, dim3(1), dim3(SS_THREADS), 0, ctx->stream, (const int4*)c, (int)n, (uint64_t*)lk,
+                     d_perm, done, (int4*)d_sorted_coords);
+  PCC_CHECK_LAUNCH();
+  return sort_pairs_impl(ctx, (uint64_t*)lk, d_perm, n, 0, done, (const int4*)c, (int4*)d_sorted_coords);
 }
 
 extern "C" int pcc_gather_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* d_perm,
