@@ -1659,6 +1659,8 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   // version 1: the streams are decoded on the device; their headers are checked here, on the host copy
   int64_t z_steps = 0, z_chunks = 0, y_steps = 0, y_chunks = 0;
   int32_t* d_status = nullptr;
+  uint8_t* d_streams_early = nullptr;   // version 1: the strings in HBM and the z symbols, when queued before the geometry
+  int32_t* zsym_early = nullptr;
   if (v1) {
     int64_t zn = 0, yn = 0;
     PCC_TRY(pcc_rans_stream_info(zstr, zlen, &zn, &z_steps, &z_chunks));
@@ -1673,6 +1675,19 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     PCC_TRY(cd->pin_dec.ensure((size_t)ylen + (size_t)zlen + 512));
     memcpy(cd->pin_dec.p, zstr, (size_t)zlen);
     memcpy(cd->pin_dec.p + (((size_t)zlen + 255) & ~(size_t)255), ystr, (size_t)ylen);
+    // ... and the z stream is decoded at once (its symbol count is what its own header says, checked against the
+    // container's above; up to kEarlyZSymbols of them, like the host job of version 0): the kernel runs while this thread
+    // decodes the octrees
+    if ((int64_t)nz_hdr * cz <= kEarlyZSymbols) {
+      const size_t zpad = ((size_t)zlen + 255) & ~(size_t)255;
+      CODEC_ALLOC(d_str, uint8_t, zpad + (size_t)ylen + 256);
+      CODEC_ALLOC(zs, int32_t, std::max<int64_t>((int64_t)nz_hdr, 1) * cz);
+      PCC_HIP(hipMemcpyAsync(d_str, cd->pin_dec.p, zpad + (size_t)ylen, hipMemcpyHostToDevice, st));
+      PCC_TRY(pcc_rans_decode_dev(ctx, cd->eb_dev, d_str, zlen, (int64_t)nz_hdr * cz, z_steps, z_chunks, nullptr,
+                                  std::max<int64_t>(nz_hdr, 1), zs, d_status));
+      d_streams_early = d_str;
+      zsym_early = zs;
+    }
   }
 
   // ---- step 2: latent coordinates of every frame (codec_parallel.py:266-289)
@@ -1754,15 +1769,21 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   uint8_t* d_ystr = nullptr;
   {
     const int64_t nz = zcs->n;
-    CODEC_ALLOC(zsym_d, int32_t, std::max<int64_t>(nz, 1) * cz);
+    CODEC_ALLOC(zsym_d_own, int32_t, std::max<int64_t>(nz, 1) * cz);
+    int32_t* zsym_d = zsym_d_own;
     CODEC_ALLOC(rows, float, std::max<int64_t>(nz, 1) * cz);
     if (v1) {
       const size_t zpad = ((size_t)zlen + 255) & ~(size_t)255;
-      CODEC_ALLOC(d_str, uint8_t, zpad + (size_t)ylen + 256);
-      PCC_HIP(hipMemcpyAsync(d_str, cd->pin_dec.p, zpad + (size_t)ylen, hipMemcpyHostToDevice, st));
-      d_ystr = d_str + zpad;
-      PCC_TRY(pcc_rans_decode_dev(ctx, cd->eb_dev, d_str, zlen, nz * cz, z_steps, z_chunks, nullptr, std::max<int64_t>(nz, 1),
-                                  zsym_d, d_status));
+      if (zsym_early) {  // (nz == nz_hdr was checked above)
+        d_ystr = d_streams_early + zpad;
+        zsym_d = zsym_early;
+      } else {
+        CODEC_ALLOC(d_str, uint8_t, zpad + (size_t)ylen + 256);
+        PCC_HIP(hipMemcpyAsync(d_str, cd->pin_dec.p, zpad + (size_t)ylen, hipMemcpyHostToDevice, st));
+        d_ystr = d_str + zpad;
+        PCC_TRY(pcc_rans_decode_dev(ctx, cd->eb_dev, d_str, zlen, nz * cz, z_steps, z_chunks, nullptr, std::max<int64_t>(nz, 1),
+                                    zsym_d, d_status));
+      }
       if (nz > 0) PCC_TRY(pcc_factorized_dequant(ctx, zsym_d, nz, cz, cd->dev["entropy_bottleneck.medians"], rows));
     } else if (nz > 0) {
       PCC_TRY(cd->pin_zsym.ensure((size_t)nz * cz * 4));
