@@ -55,3 +55,10 @@ def test_c_program_drives_the_codec(tmp_path, wl, oracle, version):
         assert np.array_equal(xyz[offs[i]:offs[i + 1], 1:], fr["points"])
         item = np.clip(np.nan_to_num(rgb[offs[i]:offs[i + 1]], nan=0.0) * 255.0, 0, 255) / 255
         assert np.array_equal(item, fr["colors"])
+    # the host-memory entry points (pcc_encode_gop_host_frames was checked against pcc_encode_gop inside the program):
+    # pcc_decode_gop_packed's arrays are the frames as pack_batches returns them
+    pxyz = np.fromfile(prefix + ".pxyz.i32", np.int32).reshape(-1, 3)
+    prgb = np.fromfile(prefix + ".prgb.f32", np.float32).reshape(-1, 3)
+    for i, fr in enumerate(oref):
+        assert np.array_equal(pxyz[offs[i]:offs[i + 1]], fr["points"])
+        assert np.array_equal(prgb[offs[i]:offs[i + 1]], fr["colors"])
