@@ -1035,7 +1035,10 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     } else {
       PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
     }
-    PCC_TRY(pcc_sort_pairs(ctx, keys, perm, n, 0));
+    // Morton keys of int16 coordinates fill bytes 0-5, the frame index the bytes above: the passes are known without a
+    // look at the keys (and without the host round trip behind it); a byte that happens to be constant costs one
+    // no-op pass
+    PCC_TRY(pcc_sort_pairs_bytes(ctx, keys, perm, n, 0x3Fu | (n_frames > 1 ? 0x40u : 0u) | (n_frames > 256 ? 0x80u : 0u)));
     PCC_TRY(cd->pin_flag.ensure(64 + 16 * PCC_MAX_FRAMES_ARG));
     PCC_HIP(hipMemcpyAsync(cd->pin_flag.p, flag, 4, hipMemcpyDeviceToHost, st));
     if (frames) {  // the octree roots of the geometry slots follow from these (octree_root drops the low 9 key bits)

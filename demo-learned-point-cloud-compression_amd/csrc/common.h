@@ -81,6 +81,8 @@ bool pcc_conv_up_fused();
 // conv.hip: frees the operand-ordered weight copies of a context (pcc_destroy)
 void pcc_wcache_free(pcc_ctx* ctx);
 // conv.hip: pcc_sparse_conv_head_up on input rows whose 32 channels are stored in the order kConv16Perm below
+// sort.hip: pcc_sort_pairs on given key bytes only (no look at the keys, no host round trip)
+int pcc_sort_pairs_bytes(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n, unsigned byte_mask);
 // sort.hip: canonical order + rows in that order of a small coordinate set given by its Morton keys
 int64_t pcc_sort_small_max();
 int pcc_sort_keys_canonical(pcc_ctx* ctx, const uint64_t* d_mkeys, int64_t n, uint32_t* d_perm, int32_t* d_sorted_coords);

@@ -335,9 +335,12 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint64_t* __restrict_
 }
 
 // Sort with scratch already reserved in the arena.
+// byte_mask (0 = find out): the key bytes to sort on, when the caller knows which can vary — saves the pass over the
+// keys that finds the varying bytes and the host round trip behind it; a pass on a byte that happens to be constant
+// is a stable no-op, so a superset is always correct.
 static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
                            int is_signed, const int* d_done = nullptr, const int4* d_rows = nullptr,
-                           int4* d_sorted = nullptr) {
+                           int4* d_sorted = nullptr, unsigned byte_mask = 0) {
   hipStream_t st = ctx->stream;
   if (n <= 0) return PCC_OK;
   if (n == 1) {
@@ -361,18 +364,24 @@ static int sort_pairs_impl(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int
   const size_t arena_mark = ctx->arena_off;
 
   // which digits vary?
-  unsigned long long init[2] = {0ull, ~0ull};
-  unsigned long long* h = (unsigned long long*)ctx->pinned;
-  h[0] = init[0];
-  h[1] = init[1];
-  PCC_HIP(hipMemcpyAsync(orand, h, 16, hipMemcpyHostToDevice, st));
-  unsigned g = nblk(n, 256);
-  if (g > 512) g = 512;
-  hipLaunchKernelGGL(k_key_bits, dim3(g), dim3(256), 0, st, d_keys, n, orand);
-  PCC_CHECK_LAUNCH();
-  PCC_HIP(hipMemcpyAsync(h, orand, 16, hipMemcpyDeviceToHost, st));
-  PCC_HIP(hipStreamSynchronize(st));
-  const uint64_t varying = h[0] & ~h[1];
+  uint64_t varying = 0;
+  if (byte_mask) {
+    for (int p = 0; p < 8; ++p)
+      if ((byte_mask >> p) & 1u) varying |= 0xFFull << (8 * p);
+  } else {
+    unsigned long long init[2] = {0ull, ~0ull};
+    unsigned long long* h = (unsigned long long*)ctx->pinned;
+    h[0] = init[0];
+    h[1] = init[1];
+    PCC_HIP(hipMemcpyAsync(orand, h, 16, hipMemcpyHostToDevice, st));
+    unsigned g = nblk(n, 256);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(k_key_bits, dim3(g), dim3(256), 0, st, d_keys, n, orand);
+    PCC_CHECK_LAUNCH();
+    PCC_HIP(hipMemcpyAsync(h, orand, 16, hipMemcpyDeviceToHost, st));
+    PCC_HIP(hipStreamSynchronize(st));
+    varying = h[0] & ~h[1];
+  }
   const uint64_t flip = is_signed ? (1ull << 63) : 0ull;
 
   uint64_t* kin = d_keys;
@@ -487,6 +496,18 @@ extern "C" int pcc_linear_keys(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
                      (const int4*)d_coords, n, d_keys);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
+}
+
+// internal (common.h): pcc_sort_pairs on the key bytes of byte_mask only (bit p = byte p), without looking at the keys
+// first — for callers that know which bytes can differ (codec.hip: Morton keys of int16 coordinates vary in bytes 0-5,
+// the frame index sits above them)
+int pcc_sort_pairs_bytes(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n, unsigned byte_mask) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_keys && d_perm)) && byte_mask != 0 && byte_mask < 256, PCC_E_ARG,
+              "pcc_sort_pairs_bytes: bad argument");
+  PCC_REQUIRE(n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_sort_pairs_bytes: n too large");
+  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n)));
+  PccProfScope prof(ctx, "sort_pairs", n, 0, 0, 0);
+  return sort_pairs_impl(ctx, d_keys, d_perm, n, 0, nullptr, nullptr, nullptr, byte_mask);
 }
 
 extern "C" int pcc_sort_pairs(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n,
