@@ -256,6 +256,10 @@ struct pcc_codec {
   Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec, pin_up;
   hipStream_t up_stream = nullptr;     // host frames cross PCIe on this stream while the compute stream sorts (encode_gop_impl)
   hipEvent_t up_done = nullptr;
+  // events of a call (symbol pieces, geometry slot): created once, handed out again by every call (creating and
+  // destroying half a dozen per GOP is host time on the path)
+  std::vector<hipEvent_t> events;
+  size_t events_used = 0;
   std::deque<CS> sets;
   std::vector<std::vector<uint8_t>> out;  // containers of the last encode
   // reconstruction of the last decode (device, pool-owned: valid until the next call)
@@ -450,6 +454,17 @@ struct View {
   uint32_t* perm = nullptr;
   int64_t n = 0;
 };
+
+// an event of the codec's pool for this call (cd->events_used is reset where the call resets the device pool)
+int call_event(pcc_codec* cd, hipEvent_t* out) {
+  if (cd->events_used == cd->events.size()) {
+    hipEvent_t e = nullptr;
+    PCC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    cd->events.push_back(e);
+  }
+  *out = cd->events[cd->events_used++];
+  return PCC_OK;
+}
 
 int view_of(pcc_codec* cd, CS* s, View* v) {
   const int64_t cap = std::max<int64_t>(s->n, 1);
@@ -657,6 +672,36 @@ int rans_encode_grow(const int32_t* sym, const int32_t* idx, int64_t n, const Te
 
 // ======================================================================== C-ABI
 
+// The runtime sets a transfer path up the first time it is used (another copy engine while the first is busy, a size
+// class, a direction): ~5 ms, once per process — and when that first time fell into a GOP, that GOP took twice as long
+// (seen as one run in four of bench.py reading 96 instead of 100 frames/s).  A codec therefore walks through transfers
+// of the kinds its calls make — small and medium ones, both directions, several in flight — when it is created.
+// Best effort: a failure here is not an error of the codec.
+static void warm_copy_paths(pcc_codec* cd) {
+  hipStream_t st = cd->ctx->stream;
+  const size_t big = (size_t)1 << 20;
+  uint8_t *d = nullptr, *h = nullptr;
+  if (hipMalloc((void**)&d, 2 * big) != hipSuccess) return;
+  if (hipHostMalloc((void**)&h, 2 * big, hipHostMallocDefault) == hipSuccess) {
+    for (int rep = 0; rep < 2; ++rep) {
+      for (size_t bytes : {(size_t)64, (size_t)4096, (size_t)65536, big}) {
+        for (int k = 0; k < 4; ++k) {
+          (void)hipMemcpyAsync(h + (size_t)k * (big / 4), d + (size_t)k * (big / 4), std::min(bytes, big / 4), hipMemcpyDeviceToHost, st);
+          (void)hipMemcpyAsync(d + big + (size_t)k * (big / 4), h + big + (size_t)k * (big / 4), std::min(bytes, big / 4),
+                               hipMemcpyHostToDevice, st);
+        }
+        (void)hipMemcpy2DAsync(h, 4096, d, 4096, std::min(bytes, (size_t)4096), 3, hipMemcpyDeviceToHost, st);
+      }
+      (void)hipMemsetAsync(d, 0, 4096, st);
+      (void)hipMemcpyAsync(d + big, d, 65536, hipMemcpyDeviceToDevice, st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipHostFree(h);
+  }
+  (void)hipFree(d);
+  (void)hipGetLastError();
+}
+
 extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device, void* stream) {
   if (!h_ckpt || n < 8 || memcmp(h_ckpt, "PCCW", 4) != 0) {
     pcc_set_error("pcc_codec_create: not a PCCW checkpoint blob");
@@ -798,6 +843,7 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
       cd->eb_dev = pcc_rans_dev_create(eb_cdf->i32(), (int)eb_cdf->dims[1], eb_len->i32(), eb_off->i32(), (int)eb_cdf->dims[0]);
     // (a table set too large for the coder's LDS image leaves the pointer null: version 1 is then refused, not faked)
   }
+  warm_copy_paths(cd);
   return cd;
 }
 
@@ -823,6 +869,7 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
     (void)hipStreamDestroy(cd->up_stream);
   }
   if (cd->up_done) (void)hipEventDestroy(cd->up_done);
+  for (hipEvent_t e : cd->events) (void)hipEventDestroy(e);
   for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec,
                     &cd->pin_up})
     p->release();
@@ -967,6 +1014,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   PCC_HIP(hipSetDevice(cd->device));
   PCC_TRY(pcc_sync(ctx));  // the previous call's tensors are dead from here on
   cd->pool.reset();
+  cd->events_used = 0;
   cd->sets.clear();
   cd->out.assign((size_t)n_q, {});
   const int cy = cd->c_y, cz = cd->c_z;
@@ -1119,13 +1167,12 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   std::vector<FrameGeo> geo((size_t)n_frames);
   double geo_dev_s = 0;
   // Asynchronous form — every frame's latent within the single-workgroup octree kernel and the frames' end keys on the
-  // host since the sort: the octree kernels and the transfers of their output are queued and an event recorded, nothing
-  // waits.  The occupancy bytes come down as a guess of 2 bytes per leaf (a surface latent has ~1.3; the rest follows
-  // if a frame has more).  geometry_finish() waits for the event.
+  // host since the sort: the octree kernels are queued and an event recorded, nothing waits.  The kernels write their
+  // (small) output — occupancy bytes and level counts — straight into pinned host memory; geometry_finish() waits for
+  // the event.
   bool geo_async = false;
-  Event geo_ev;
-  uint8_t* geo_occ_dev = nullptr;
-  std::vector<int64_t> geo_cap((size_t)n_frames, 0), geo_got((size_t)n_frames, 0);
+  hipEvent_t geo_ev = nullptr;
+  std::vector<int64_t> geo_cap((size_t)n_frames, 0);
   constexpr int kGeoCounts = 20;  // uint32 per frame in the counts block (depth + 1 <= 17 used)
   auto geometry_device_half = [&]() -> int {
     const double tg = now_s();
@@ -1146,22 +1193,18 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
           cap_total += geo_cap[f];
         }
       }
-      CODEC_ALLOC(occ, uint8_t, std::max<int64_t>(cap_total, 1));
-      CODEC_ALLOC(cnt, uint32_t, kGeoCounts * n_frames);
-      geo_occ_dev = occ;
       PCC_TRY(cd->pin_occ.ensure((size_t)std::max<int64_t>(cap_total, 1)));
       PCC_TRY(cd->pin_keys.ensure((size_t)kGeoCounts * 4 * n_frames));
-      if (!geo_ev.e) PCC_TRY(geo_ev.create());
+      if (!geo_ev) PCC_TRY(call_event(cd, &geo_ev));
       for (int f = 0; f < n_frames; ++f) {
         FrameGeo& g = geo[f];
         if (g.n == 0) continue;
-        PCC_TRY(pcc_octree_small_async(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, occ + g.occ_off, geo_cap[f],
-                                       cnt + kGeoCounts * f));
-        geo_got[f] = std::min<int64_t>(geo_cap[f], (2 * g.n + 255) & ~(int64_t)255);
-        PCC_HIP(hipMemcpyAsync(cd->pin_occ.p + g.occ_off, occ + g.occ_off, (size_t)geo_got[f], hipMemcpyDeviceToHost, st));
+        // the kernel writes its (small) output straight into the pinned host buffers — they are device-accessible —
+        // so the slot needs no transfer of its own
+        PCC_TRY(pcc_octree_small_async(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, cd->pin_occ.p + g.occ_off, geo_cap[f],
+                                       (uint32_t*)cd->pin_keys.p + kGeoCounts * f));
       }
-      PCC_HIP(hipMemcpyAsync(cd->pin_keys.p, cnt, (size_t)kGeoCounts * 4 * n_frames, hipMemcpyDeviceToHost, st));
-      PCC_HIP(hipEventRecord(geo_ev.e, st));
+      PCC_HIP(hipEventRecord(geo_ev, st));
       geo_async = true;
       geo_dev_s = now_s() - tg;
       return PCC_OK;
@@ -1201,9 +1244,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   // the device half has arrived (asynchronous form): level counts, and the occupancy bytes the guess did not cover
   auto geometry_arrived = [&]() -> int {
     if (!geo_async) return PCC_OK;
-    PCC_HIP(hipEventSynchronize(geo_ev.e));
+    PCC_HIP(hipEventSynchronize(geo_ev));
     const uint32_t* hc = (const uint32_t*)cd->pin_keys.p;
-    bool more = false;
     for (int f = 0; f < n_frames; ++f) {
       FrameGeo& g = geo[f];
       if (g.n == 0) continue;
@@ -1215,13 +1257,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       PCC_REQUIRE(g.level_n[0] == 1 && g.occ_len <= g.n * g.depth, PCC_E_ARG,
                   "pcc_encode_gop: octree of frame %d: %lld root nodes, %lld nodes for %lld leaves", f,
                   (long long)g.level_n[0], (long long)g.occ_len, (long long)g.n);
-      if (g.occ_len > geo_got[f]) {
-        PCC_HIP(hipMemcpyAsync(cd->pin_occ.p + g.occ_off + geo_got[f], geo_occ_dev + g.occ_off + geo_got[f],
-                               (size_t)(g.occ_len - geo_got[f]), hipMemcpyDeviceToHost, st));
-        more = true;
-      }
     }
-    if (more) PCC_HIP(hipStreamSynchronize(st));
     return PCC_OK;
   };
 
@@ -1391,7 +1427,6 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     const int n_chunks = per >= (1 << 16) ? 4 : 1;
     std::vector<int64_t> bound((size_t)n_chunks);
     for (int c = 0; c < n_chunks; ++c) bound[c] = (per * (n_chunks - 1 - c) / n_chunks) & ~(int64_t)63;
-    std::vector<Event> ev_own((size_t)n_chunks);
     std::vector<hipEvent_t> evc((size_t)n_chunks, nullptr);
     for (int c = 0; c < n_chunks; ++c) {
       const int64_t lo = bound[c], hi = c == 0 ? per : bound[c - 1];
@@ -1401,8 +1436,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         PCC_HIP(hipMemcpy2DAsync(cd->pin_yidx.p + (size_t)lo, (size_t)per, idx8 + lo, (size_t)per, (size_t)(hi - lo),
                                  (size_t)n_q, hipMemcpyDeviceToHost, st));
       }
-      PCC_REQUIRE(ev_own[c].create() == PCC_OK, PCC_E_HIP, "pcc_encode_gop: hipEventCreate failed");
-      evc[c] = ev_own[c].e;
+      PCC_TRY(call_event(cd, &evc[c]));
       PCC_HIP(hipEventRecord(evc[c], st));
     }
     struct GateUser {
@@ -1561,6 +1595,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   PCC_HIP(hipSetDevice(cd->device));
   PCC_TRY(pcc_sync(ctx));
   cd->pool.reset();
+  cd->events_used = 0;
   cd->sets.clear();
   cd->rec_n = 0;
   cd->rec_offsets.clear();
