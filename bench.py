@@ -207,6 +207,11 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # per-step spread on stderr: one GOP that takes twice as long (a one-time set-up inside the runtime, a throttled
+        # host) shows here, not in the mean
+        log(f"[rank {rank}] per-step ms ({'host' if host else 'hbm'} frames): encode min / median / max "
+            f"{min(e_ms):.2f} / {float(np.median(e_ms)):.2f} / {max(e_ms):.2f}, decode "
+            f"{min(d_ms):.2f} / {float(np.median(d_ms)):.2f} / {max(d_ms):.2f}")
         return dt, float(np.mean(e_ms)), float(np.mean(d_ms)), last
 
     # timed region (`value`): K steps of the operator contract, host numpy in / host numpy out.  Only the dominant

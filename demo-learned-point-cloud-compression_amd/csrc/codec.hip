@@ -690,7 +690,9 @@ static void warm_copy_paths(pcc_codec* cd) {
           (void)hipMemcpyAsync(d + big + (size_t)k * (big / 4), h + big + (size_t)k * (big / 4), std::min(bytes, big / 4),
                                hipMemcpyHostToDevice, st);
         }
-        (void)hipMemcpy2DAsync(h, 4096, d, 4096, std::min(bytes, (size_t)4096), 3, hipMemcpyDeviceToHost, st);
+        // (the symbol pieces of a version-0 encode: a few rows of up to several hundred KB each)
+        (void)hipMemcpy2DAsync(h, big / 4, d, big / 4, std::min(bytes, big / 4), 3, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpy2DAsync(h + big, big / 4, d + big, big / 4, std::min(bytes, big / 4) / 2 + 1, 3, hipMemcpyDeviceToHost, st);
       }
       (void)hipMemsetAsync(d, 0, 4096, st);
       (void)hipMemcpyAsync(d + big, d, 65536, hipMemcpyDeviceToDevice, st);
