@@ -356,12 +356,19 @@ static int weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cout, cons
 }
 
 // one k_gconv16 launch.  Grid rounded up to a multiple of 8 workgroups: the kernel maps workgroup -> window per XCD.
+// Launches of fewer than kSmallLaunchRows rows (less than one round of 64-row windows on the chip's 4096 wave
+// slots) take 32-row windows: such a launch lasts as long as one window, and a 32-row window is the shorter one.
+constexpr int64_t kSmallLaunchRows = 200000;
 template <bool HEAD, bool UP, bool PERM, int COUT>
 static void launch16(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch, int64_t n_out,
                      const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
                      float* ho, const float* cw = nullptr, const float* cb = nullptr, float* co = nullptr) {
-  hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT>), dim3((nblk(n_out, 64) + 7) / 8 * 8, COUT / 32), dim3(64), 0, st,
-                     d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+  if (n_out < kSmallLaunchRows)
+    hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 32>), dim3((nblk(n_out, 32) + 7) / 8 * 8, COUT / 32), dim3(64), 0, st,
+                       d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+  else
+    hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 64>), dim3((nblk(n_out, 64) + 7) / 8 * 8, COUT / 32), dim3(64), 0, st,
+                       d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
 }
 
 static bool conv16_shape(const float* d_in, const float* d_out, int k_vol, int cin, int cout) {

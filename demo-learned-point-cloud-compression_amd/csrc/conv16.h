@@ -86,23 +86,26 @@ __global__ __launch_bounds__(256) void k_conv16_swizzle(const float* __restrict_
   wsw[t] = w[(k * 32 + 4 * s + q) * cout + 32 * y + 16 * hi + m];
 }
 
-template <bool HEAD, bool UP, bool PERM, int COUT = 32>
+// R (rows of a window, 64 or 32): a launch of a few hundred 64-row windows is one partial round of waves on 1024 SIMDs
+// — it lasts as long as ONE window (27 dependent steps) whatever its size.  Such launches run on 32-row windows: twice
+// the waves, about half the records (and items) per step and wave; lanes 32..63 own no row and only help to carry.
+template <bool HEAD, bool UP, bool PERM, int COUT = 32, int R = 64>
 __global__ __launch_bounds__(64) void k_gconv16(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
     float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
     float* __restrict__ head_out, const float* __restrict__ rgb_w = nullptr, const float* __restrict__ rgb_b = nullptr,
     float* __restrict__ rgb_out = nullptr) {
-  constexpr int R = 64;    // rows of the window
+  static_assert(R == 64 || R == 32, "window of 64 or 32 rows");
   // Accumulators in LDS: two planes (channels 0..15, 16..31) of 16-float rows; the 16-B piece q of a row sits at
   // position (q + 2 (row >> 2)) & 3 of its plane row.  The hardware serves a ds_read_b128 / ds_write_b128 in groups of 16
   // lanes that hold 16 different slots and two values of q; with a plain row-major layout (any pitch) consecutive rows
   // then collide pairwise (SQ_LDS_BANK_CONFLICT was 40 % of SQ_LDS_IDX_ACTIVE), with this placement an item of 16
   // consecutive rows is conflict-free and compacted row lists collide only by chance.
   constexpr int HP = (R + 1) * 16;   // floats per plane (row R = sink of the pad slots)
-  constexpr int NI = 4;    // items an offset can have
+  constexpr int NI = R / 16;   // items an offset can have
   __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
-  __shared__ __attribute__((aligned(8))) int2 rec[2][R];                 // slot -> (input row, accumulator row)
+  __shared__ __attribute__((aligned(8))) int2 rec[2][64];                // slot -> (input row, accumulator row); every LANE writes one
 
   static_assert(COUT == 32 || (COUT == 64 && !HEAD), "the fused head reads all channels of a row");
   const int lane = threadIdx.x;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
 
   // ---- neighbour index of this lane's row: requested two offsets ahead, turned into a row one offset later
   const int64_t r_own = row0 + lane;
-  const bool row_ok = r_own < n_out;
+  const bool row_ok = lane < R && r_own < n_out;
   const int64_t rc = row_ok ? r_own : n_out - 1;
   int32_t nb_raw = -1;   // UP: row of the parent-level neighbour; else the neighbour row itself
   int nb_op = 0;         // UP: octant of the neighbour inside that parent
@@ -287,8 +290,10 @@ __global__ __launch_bounds__(64) void k_gconv16(
     }                                                                                                  \
     gather(g)
     PCC16_ITEM(1, lo1, hi1, lo0, hi0);
-    PCC16_ITEM(2, lo0, hi0, lo1, hi1);
-    PCC16_ITEM(3, lo1, hi1, lo0, hi0);
+    if constexpr (NI > 2) {
+      PCC16_ITEM(2, lo0, hi0, lo1, hi1);
+      PCC16_ITEM(3, lo1, hi1, lo0, hi0);
+    }
 #undef PCC16_ITEM
     PCC_STAMP(2);
     cnt_cur = cnt_next;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
     float hv = head_b[0];
 #pragma unroll
     for (int c4 = 0; c4 < 8; ++c4) {
-      const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, lane, c4 & 3)]);
+      const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, lane < R ? lane : R, c4 & 3)]);
       const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
       float cv[3] = {rgb_b[0], rgb_b[1], rgb_b[2]};
 #pragma unroll
       for (int c4 = 0; c4 < 8; ++c4) {
-        const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, lane, c4 & 3)]);
+        const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, lane < R ? lane : R, c4 & 3)]);
         const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

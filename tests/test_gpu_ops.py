@@ -437,6 +437,38 @@ def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
     assert np.array_equal(got, oracle.map27(ckeys[keep], 1))
 
 
+@pytest.mark.parametrize("kind", ["dense", "dust"])
+def test_conv32_large_launch_bit_exact(rt, oracle, kind):
+    """launches of 200k rows and more run on 64-row windows (smaller ones on 32-row windows: the tests above): the same
+    entry points just past that size, a ragged last window included"""
+    rng = np.random.default_rng(4242)
+    n = 200_000 + 77
+    keys = sorted_keys(oracle, _structured_cloud(kind, n))
+    assert len(keys) >= 200_000
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(len(keys), 32)).astype(np.float32)
+    w, b = _weights(rng, 27, 32, 32)
+    hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
+    hb = rng.normal(0, 0.1, 1).astype(np.float32)
+    ref = oracle.sparse_conv(x, nbr, w, b, True)
+    feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw), dev(rt, hb))
+    assert np.array_equal(host(feats), ref)
+    assert np.array_equal(host(logits), oracle.linear(ref, hw, hb)[:, 0])
+    w64, b64 = _weights(rng, 27, 32, 64)
+    out64 = rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w64), dev(rt, b64), False)
+    assert np.array_equal(host(out64), oracle.sparse_conv(x, nbr, w64, b64, False))
+    # the in-kernel child rule book on 8 x 25_010 candidates
+    pkeys = sorted_keys(oracle, _structured_cloud(kind, 25_010) * 2)
+    nbr_p = oracle.map27(pkeys, 2)
+    ckeys = oracle.up(pkeys, 2)
+    assert len(ckeys) >= 200_000
+    xc = rng.normal(size=(len(ckeys), 32)).astype(np.float32)
+    refc = oracle.sparse_conv(xc, oracle.map27(ckeys, 1), w, b, True)
+    fc, lc = rt.sparse_conv_head_up(dev(rt, xc), dev(rt, nbr_p), dev(rt, w), dev(rt, b), True, dev(rt, hw), dev(rt, hb))
+    assert np.array_equal(host(fc), refc)
+    assert np.array_equal(host(lc), oracle.linear(refc, hw, hb)[:, 0])
+
+
 def test_conv_head_up_refuses_under_the_scalar_switch(rt):
     """the form with the in-kernel rule book exists only as an MFMA kernel: under PCC_FORCE_SCALAR=1 it must be
     refused (the decoder then materialises the child rule books), not silently computed by something else"""
