@@ -695,6 +695,33 @@ def test_gaussian_quant_indexes_dequant(rt, oracle):
     assert np.array_equal(host(yh), oracle.gaussian_dequant(rs[2], params, scale[2]))
 
 
+def test_gaussian_indexes_keep_the_counting_definition(rt, oracle):
+    """build_indexes counts table entries >= the scale (compressai entropy_models.py GaussianConditional.build_indexes).
+    The kernels take a lower-bound search when the table ascends: exact ties, NaN scales and a table that does NOT ascend
+    (the count, not the search, is the definition) must give the oracle's indexes."""
+    rng = np.random.default_rng(23)
+    n, c = 333, 32
+    table = np.ascontiguousarray(oracle.t["gaussian_conditional.scale_table"], dtype=np.float32)
+    params = np.concatenate([np.abs(rng.normal(1.5, 3.0, (n, c))), rng.normal(0, 1, (n, c))], 1).astype(np.float32)
+    one = np.ones(c, dtype=np.float32)
+    params[:64, 0] = table           # ties with every table entry (scale 1.0 keeps them exact)
+    params[64:70, 1] = np.nan
+    params[70:72, 2] = np.inf
+    y = rng.normal(size=(n, c)).astype(np.float32)
+    saved = oracle.t["gaussian_conditional.scale_table"]
+    try:
+        for tab_h in (table, table[::-1].copy(), rng.permutation(table)):
+            oracle.t["gaussian_conditional.scale_table"] = tab_h
+            tab = dev(rt, tab_h)
+            want = oracle.gaussian_indexes(params, one)
+            assert np.array_equal(host(rt.gaussian_indexes(dev(rt, params), dev(rt, one), tab)), want)
+            assert np.array_equal(host(rt.gaussian_indexes8(dev(rt, params), dev(rt, one), tab)).astype(np.int32), want)
+            _, idx = rt.gaussian_quant(dev(rt, y), dev(rt, params), dev(rt, one[None, :]), tab)
+            assert np.array_equal(host(idx)[0], want)
+    finally:
+        oracle.t["gaussian_conditional.scale_table"] = saved
+
+
 # ---------------------------------------------------------------- octree
 @pytest.mark.parametrize("name", ["surf", "tiny", "one", "rand"])
 def test_octree_blob_matches_oracle_and_round_trips(rt, oracle, clouds, name):
