@@ -359,16 +359,37 @@ static int weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cout, cons
 // Launches of fewer than kSmallLaunchRows rows (less than one round of 64-row windows on the chip's 4096 wave
 // slots) take 32-row windows: such a launch lasts as long as one window, and a 32-row window is the shorter one.
 constexpr int64_t kSmallLaunchRows = 200000;
-template <bool HEAD, bool UP, bool PERM, int COUT>
-static void launch16(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch, int64_t n_out,
-                     const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
-                     float* ho, const float* cw = nullptr, const float* cb = nullptr, float* co = nullptr) {
+// PCC_CONV_WIDE_ROWS=1 in the environment (read once): every launch takes the 64-bit row arithmetic that tensors of
+// 2^25 rows and more need — how the tests reach that form without a 4-GB tensor.
+static bool force_wide_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PCC_CONV_WIDE_ROWS");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+template <bool HEAD, bool UP, bool PERM, int COUT, bool WIDE>
+static void launch16w(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch, int64_t n_out,
+                      const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
+                      float* ho, const float* cw, const float* cb, float* co) {
   if (n_out < kSmallLaunchRows)
-    hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 32>), dim3((nblk(n_out, 32) + 7) / 8 * 8, COUT / 32), dim3(64), 0, st,
-                       d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+    hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 32, WIDE>), dim3((nblk(n_out, 32) + 7) / 8 * 8, COUT / 32), dim3(64), 0,
+                       st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
   else
-    hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 64>), dim3((nblk(n_out, 64) + 7) / 8 * 8, COUT / 32), dim3(64), 0, st,
-                       d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+    hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 64, WIDE>), dim3((nblk(n_out, 64) + 7) / 8 * 8, COUT / 32), dim3(64), 0,
+                       st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+}
+// n_in: rows of d_in (the byte offset of a row must fit 32 bits for the narrow form; UP: its parent book's pitch 24)
+template <bool HEAD, bool UP, bool PERM, int COUT>
+static void launch16(hipStream_t st, const float* d_in, int64_t n_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
+                     int64_t n_out, const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw,
+                     const float* hb, float* ho, const float* cw = nullptr, const float* cb = nullptr, float* co = nullptr) {
+  const bool wide = n_in > ((int64_t)1 << 25) || (UP && pitch >= ((int64_t)1 << 24)) || force_wide_rows();
+  if (wide)
+    launch16w<HEAD, UP, PERM, COUT, true>(st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+  else
+    launch16w<HEAD, UP, PERM, COUT, false>(st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
 }
 
 static bool conv16_shape(const float* d_in, const float* d_out, int k_vol, int cin, int cout) {
@@ -395,9 +416,9 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
     PCC_TRY(weights_for(ctx, d_w, k_vol, cout, &wsw));
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
     if (cout == 32)
-      launch16<false, false, false, 32>(st, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
+      launch16<false, false, false, 32>(st, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
     else
-      launch16<false, false, false, 64>(st, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
+      launch16<false, false, false, 64>(st, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
   } else if (!force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 && cout == 32) {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
     hipLaunchKernelGGL(k_gconv_first, dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
@@ -422,7 +443,7 @@ extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_i
     const float* wsw;
     PCC_TRY(weights_for(ctx, d_w, k_vol, cout, &wsw));
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
-    launch16<true, false, false, 32>(ctx->stream, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, d_head_w,
+    launch16<true, false, false, 32>(ctx->stream, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, d_head_w,
                                      d_head_b, d_head_out);
     PCC_CHECK_LAUNCH();
     return PCC_OK;
@@ -451,10 +472,10 @@ static int head_up_impl(pcc_ctx* ctx, const float* d_in, int64_t n_parents, cons
   PCC_TRY(weights_for(ctx, d_w, 27, 32, &wsw));
   PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
   if (in_perm)
-    launch16<true, true, true, 32>(ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out,
+    launch16<true, true, true, 32>(ctx->stream, d_in, n_out, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out,
                                    d_head_w, d_head_b, d_head_out);
   else
-    launch16<true, true, false, 32>(ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out,
+    launch16<true, true, false, 32>(ctx->stream, d_in, n_out, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out,
                                     d_head_w, d_head_b, d_head_out);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
@@ -495,7 +516,7 @@ int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_
   const float* wsw;
   PCC_TRY(weights_for(ctx, d_w, 27, 32, &wsw));
   PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
-  launch16<true, true, true, 32>(ctx->stream, d_in, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, nullptr,
+  launch16<true, true, true, 32>(ctx->stream, d_in, n_out, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, nullptr,
                                  d_head_w, d_head_b, d_head_out, d_rgb_w, d_rgb_b, d_rgb_out);
   PCC_CHECK_LAUNCH();
   return PCC_OK;

@@ -89,7 +89,15 @@ __global__ __launch_bounds__(256) void k_conv16_swizzle(const float* __restrict_
 // R (rows of a window, 64 or 32): a launch of a few hundred 64-row windows is one partial round of waves on 1024 SIMDs
 // — it lasts as long as ONE window (27 dependent steps) whatever its size.  Such launches run on 32-row windows: twice
 // the waves, about half the records (and items) per step and wave; lanes 32..63 own no row and only help to carry.
-template <bool HEAD, bool UP, bool PERM, int COUT = 32, int R = 64>
+//
+// WIDE = false (every launch whose input tensor is below 4 GB, i.e. < 2^25 rows, and whose parent rule book has a pitch
+// below 2^24): a slot record holds the BYTE offset of its input row and the LDS byte address of its accumulator row, so
+// a gather is `global_load v, voffset, s[base]` on a 32-bit offset (one v_or per gather instead of a sign extension, a
+// 64-bit shift and a 64-bit add), an accumulator address one v_xor with the lane's piece (instead of five instructions,
+// twice per item), and the parent-book index of the UP form one v_mul_u32_u24 (instead of a 64-bit product built from
+// three quarter-rate multiplies).  f32 MFMAs share the vector ALUs, so every vector instruction saved is
+// matrix time gained.  WIDE = true keeps 64-bit row arithmetic for tensors beyond those bounds.
+template <bool HEAD, bool UP, bool PERM, int COUT = 32, int R = 64, bool WIDE = false>
 __global__ __launch_bounds__(64) void k_gconv16(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
   constexpr int HP = (R + 1) * 16;   // floats per plane (row R = sink of the pad slots)
   constexpr int NI = R / 16;   // items an offset can have
   __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
-  __shared__ __attribute__((aligned(8))) int2 rec[2][64];                // slot -> (input row, accumulator row); every LANE writes one
+  __shared__ __attribute__((aligned(8))) int2 rec[2][64];                // slot -> (input row [WIDE] or its byte offset, accumulator row address acc_row); every LANE writes one
 
   static_assert(COUT == 32 || (COUT == 64 && !HEAD), "the fused head reads all channels of a row");
   const int lane = threadIdx.x;
@@ -121,6 +129,11 @@ __global__ __launch_bounds__(64) void k_gconv16(
 
   // float index of channel block (plane `half`, piece qq) of `row`
   auto acc_at = [&](int half, int row, int qq) -> int { return half * HP + row * 16 + (((qq + 2 * (row >> 2)) & 3) << 2); };
+  // the same as a byte address in plane 0, in two parts: (qq + 2 (row >> 2)) & 3 == qq ^ ((row >> 1) & 2), so
+  // 4 * acc_at(0, row, qq) == acc_row(row) ^ (qq << 4): the row's part travels in the slot record, the lane's is a constant
+  auto acc_row = [](int row) -> int { return row * 64 + (((row >> 1) & 2) << 4); };
+  const int a_own = acc_row(lane), a_sink = acc_row(R), q16 = q << 4;
+  const uint32_t qoff = (uint32_t)q * 32u;   // bytes: channels 8q .. of an input row
   {  // accumulators start at the bias: lane (grow, chunk) fills piece `chunk` (channels 4 chunk ..) of rows grow + 8 it
     const float* bp = bias + col0 + chunk * 4;
     const float4 b4 = make_float4(bp[0], bp[1], bp[2], bp[3]);
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
   const int64_t r_own = row0 + lane;
   const bool row_ok = lane < R && r_own < n_out;
   const int64_t rc = row_ok ? r_own : n_out - 1;
+  const uint32_t rc3 = (uint32_t)(rc >> 3);
   int32_t nb_raw = -1;   // UP: row of the parent-level neighbour; else the neighbour row itself
   int nb_op = 0;         // UP: octant of the neighbour inside that parent
   bool nb_live = false;  // offset exists and the lane owns a row
@@ -145,7 +159,13 @@ __global__ __launch_bounds__(64) void k_gconv16(
       const int tx = ((o >> 2) & 1) + (kk / 9) - 1, ty = ((o >> 1) & 1) + ((kk / 3) % 3) - 1, tz = (o & 1) + (kk % 3) - 1;
       const int kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
       nb_op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
-      nb_raw = nbr[(int64_t)kp * pitch + (rc >> 3)];
+      if constexpr (WIDE) {
+        nb_raw = nbr[(int64_t)kp * pitch + (rc >> 3)];
+      } else {
+        // pitch < 2^24 and kp < 27: the index and its byte offset fit 32 bits
+        const uint32_t off = (__umul24((uint32_t)kp, (uint32_t)pitch) + rc3) << 2;
+        nb_raw = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(nbr) + off);
+      }
     } else {
       nb_raw = nbr[(int64_t)kk * pitch + rc];
     }
@@ -159,16 +179,19 @@ __global__ __launch_bounds__(64) void k_gconv16(
     const unsigned long long bal = __ballot(p);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
     const int cnt = __popcll(bal);
-    rec[b][p ? rank : cnt + lane - rank] = p ? make_int2(src, lane) : make_int2(0, R);
+    const int32_t sx = WIDE ? src : (int32_t)((uint32_t)src << 7);
+    rec[b][p ? rank : cnt + lane - rank] = p ? make_int2(sx, a_own) : make_int2(0, a_sink);
     return cnt;
   };
 
   float4 G[NI][2];              // gathered rows (B operands) of the items of one offset
   float4 W0[4], W1[4];          // A operands of the even / odd offsets
   int rin[NI], ra0[NI], ra1[NI];  // input rows of the next offset's slots; accumulator rows (byte offsets) even / odd
+  const uint32_t lane64 = (uint32_t)lane * 64u;
   auto load_w = [&](float4 (&W)[4], int k) {
     const int kk = k < k_vol ? k : k_vol - 1;
-    const float4* p = reinterpret_cast<const float4*>(wsw + (((int64_t)kk * ny + ycol) * 64 + lane) * 16);
+    const char* base = reinterpret_cast<const char*>(wsw + ((int64_t)kk * ny + ycol) * 1024);   // uniform
+    const float4* p = reinterpret_cast<const float4*>(base + lane64);
 #pragma unroll
     for (int j = 0; j < 4; ++j) W[j] = p[j];
   };
@@ -181,19 +204,25 @@ __global__ __launch_bounds__(64) void k_gconv16(
     }
   };
   auto gather = [&](int g) {
-    const float* xr = in + (int64_t)rin[g] * 32 + q * 8;
-    G[g][0] = *reinterpret_cast<const float4*>(xr);
-    G[g][1] = *reinterpret_cast<const float4*>(xr + 4);
+    if constexpr (WIDE) {
+      const float* xr = in + (int64_t)rin[g] * 32 + q * 8;
+      G[g][0] = *reinterpret_cast<const float4*>(xr);
+      G[g][1] = *reinterpret_cast<const float4*>(xr + 4);
+    } else {
+      const char* xr = reinterpret_cast<const char*>(in) + ((uint32_t)rin[g] | qoff);
+      G[g][0] = *reinterpret_cast<const float4*>(xr);
+      G[g][1] = *reinterpret_cast<const float4*>(xr + 16);
+    }
   };
-  auto acc_read = [&](int row, f32x4& lo, f32x4& hi) {
-    const float* base = &acc_lds[acc_at(0, row, q)];
+  auto acc_read = [&](int arow, f32x4& lo, f32x4& hi) {
+    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(acc_lds) + (arow ^ q16));
     const float4 a = *reinterpret_cast<const float4*>(base);
     const float4 b = *reinterpret_cast<const float4*>(base + HP);
     lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w;
     hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; hi[3] = b.w;
   };
-  auto acc_write = [&](int row, const f32x4& lo, const f32x4& hi) {
-    float* base = &acc_lds[acc_at(0, row, q)];
+  auto acc_write = [&](int arow, const f32x4& lo, const f32x4& hi) {
+    float* base = reinterpret_cast<float*>(reinterpret_cast<char*>(acc_lds) + (arow ^ q16));
     *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
     *reinterpret_cast<float4*>(base + HP) = make_float4(hi[0], hi[1], hi[2], hi[3]);
   };
@@ -281,7 +310,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
       LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
       HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv[0], HI, 0, 0, 0);                            \
       acc_write(rc_[(g) - 1], PLO, PHI);                                                               \
-      if (more) acc_read(rc_[(g) + 1 < NI ? (g) + 1 : 0], PLO, PHI);                                   \
+      acc_read(more ? rc_[(g) + 1 < NI ? (g) + 1 : 0] : a_sink, PLO, PHI);                             \
       _Pragma("unroll") for (int s = 1; s < 8; ++s) {                                                  \
         LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], LO, 0, 0, 0);                          \
         HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], HI, 0, 0, 0);                          \

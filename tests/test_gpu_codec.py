@@ -232,9 +232,10 @@ def test_mfma_and_scalar_paths_agree_end_to_end(wl):
         "[h.update(f['points'].tobytes() + f['colors'].tobytes()) for f in r];"
         "print(h.hexdigest())" % ROOT)
     res = []
-    for flag in ("0", "1"):
-        env = dict(os.environ, PCC_FORCE_SCALAR=flag)
+    # third run: the MFMA kernels in the 64-bit row arithmetic that tensors of 2^25 rows and more take (conv16.h, WIDE)
+    for extra in ({"PCC_FORCE_SCALAR": "0"}, {"PCC_FORCE_SCALAR": "1"}, {"PCC_FORCE_SCALAR": "0", "PCC_CONV_WIDE_ROWS": "1"}):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])
-    assert res[0] == res[1]
+    assert res[0] == res[1] == res[2]

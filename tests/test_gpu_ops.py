@@ -469,6 +469,19 @@ def test_conv32_large_launch_bit_exact(rt, oracle, kind):
     assert np.array_equal(host(lc), oracle.linear(refc, hw, hb)[:, 0])
 
 
+def test_conv_wide_row_form_is_bit_exact():
+    """Launches whose input tensor has 2^25 rows or more (4 GB), or whose parent rule book has a pitch of 2^24 or more,
+    run k_gconv16 with 64-bit row arithmetic instead of 32-bit byte offsets in the slot records (conv16.h, WIDE).
+    PCC_CONV_WIDE_ROWS=1 (read once per process) sends every launch that way: the convolution tests of this file once
+    more under it, in a child process, against the same oracle results"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PCC_CONV_WIDE_ROWS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "conv and not switch and not wide_row"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
 def test_conv_head_up_refuses_under_the_scalar_switch(rt):
     """the form with the in-kernel rule book exists only as an MFMA kernel: under PCC_FORCE_SCALAR=1 it must be
     refused (the decoder then materialises the child rule books), not silently computed by something else"""
