@@ -148,6 +148,19 @@ __global__ __launch_bounds__(64) void k_gconv16(
   const bool row_ok = lane < R && r_own < n_out;
   const int64_t rc = row_ok ? r_own : n_out - 1;
   const uint32_t rc3 = (uint32_t)(rc >> 3);
+  // UP: byte d of an axis word = (parent-offset digit * weight of the axis in kp) | (octant bit of the axis << 5) for
+  // a step of d - 1 along the axis from this lane's octant bit `ob`
+  auto up_axis = [](int ob, int weight, int opbit) -> uint32_t {
+    uint32_t v = 0u;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int t = ob + d - 1;
+      v |= (uint32_t)((((t + 2) >> 1) * weight) | ((t & 1) ? (opbit << 5) : 0)) << (8 * d);
+    }
+    return v;
+  };
+  const int oct = (int)(rc & 7);
+  const uint32_t up_x = up_axis((oct >> 2) & 1, 9, 4), up_y = up_axis((oct >> 1) & 1, 3, 2), up_z = up_axis(oct & 1, 1, 1);
   int32_t nb_raw = -1;   // UP: row of the parent-level neighbour; else the neighbour row itself
   int nb_op = 0;         // UP: octant of the neighbour inside that parent
   bool nb_live = false;  // offset exists and the lane owns a row
@@ -155,10 +168,14 @@ __global__ __launch_bounds__(64) void k_gconv16(
     const int kk = k < k_vol ? k : k_vol - 1;
     nb_live = k < k_vol && row_ok;
     if constexpr (UP) {
-      const int o = (int)(rc & 7);
-      const int tx = ((o >> 2) & 1) + (kk / 9) - 1, ty = ((o >> 1) & 1) + ((kk / 3) % 3) - 1, tz = (o & 1) + (kk % 3) - 1;
-      const int kp = ((tx + 2) >> 1) * 9 + ((ty + 2) >> 1) * 3 + ((tz + 2) >> 1);
-      nb_op = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+      // t = octant bit + step of the offset along an axis, in -1 .. 2: the parent-level offset is (t + 2) >> 1, the octant
+      // bit of the neighbour inside that parent t & 1.  Per axis the three answers sit in one register (up_axis below)
+      // and the offset's step selects a byte: three bit-field extracts and an add instead of a dozen instructions.
+      const uint32_t comb = __builtin_amdgcn_ubfe(up_x, 8u * (uint32_t)(kk / 9), 8u) +
+                            __builtin_amdgcn_ubfe(up_y, 8u * (uint32_t)((kk / 3) % 3), 8u) +
+                            __builtin_amdgcn_ubfe(up_z, 8u * (uint32_t)(kk % 3), 8u);
+      const int kp = (int)(comb & 31u);
+      nb_op = (int)(comb >> 5);
       if constexpr (WIDE) {
         nb_raw = nbr[(int64_t)kp * pitch + (rc >> 3)];
       } else {
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
   auto compact = [&](int b) -> int {
     const bool p = nb_live && nb_raw >= 0;
     const int32_t src = UP ? ((nb_raw << 3) | nb_op) : nb_raw;
-    const unsigned long long bal = __ballot(p);
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
     const int cnt = __popcll(bal);
     const int32_t sx = WIDE ? src : (int32_t)((uint32_t)src << 7);
