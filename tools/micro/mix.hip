@@ -1,0 +1,73 @@
+// What four waves per SIMD get out of the matrix pipe when every wave alternates chains of v_mfma_f32_16x16x4_f32 with
+// vector / scalar / LDS work the way a k_gconv16 offset step does (conv16.h): per "step" M items of 16 MFMAs (two
+// interleaved chains of 8), V dependent vector instructions, S scalar instructions, optionally an accumulator tile
+// round trip through LDS per item.  Prints matrix-pipe busy = MFMAs x 32 cycles / elapsed cycles per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/mix.hip -o tools/micro/mix && tools/micro/mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int V, int S, bool LDS>
+__global__ void k(int iters, int items, unsigned long long* out, float* sink) {
+  __shared__ __attribute__((aligned(16))) float tile[16][64 * 4 + 4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  f32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+  float x = threadIdx.x * 0.001f, y = 1.0f + x;
+  int v = threadIdx.x;
+  int sacc = iters;
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int i = 0; i < iters; ++i) {
+    for (int g = 0; g < items; ++g) {
+      if (LDS) {
+        const float4 a = *reinterpret_cast<const float4*>(&tile[wave][lane * 4]);
+        lo[0] += a.x; lo[1] += a.y; lo[2] += a.z; lo[3] += a.w;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lo = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, hi, 0, 0, 0);
+      }
+      if (LDS) *reinterpret_cast<float4*>(&tile[wave][lane * 4]) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < V; ++u) asm volatile("v_mad_u32_u24 %0, %0, 3, %0" : "+v"(v));
+#pragma unroll
+    for (int u = 0; u < S; ++u) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(sacc));
+  }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  if (lane == 0) out[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0;
+  sink[blockIdx.x * blockDim.x + threadIdx.x] = lo[0] + hi[0] + (float)v + (float)sacc;
+}
+
+template <int V, int S, bool LDS>
+static void run(int waves_per_simd, int items, unsigned long long* out, float* sink) {
+  const int iters = 4000;
+  const int threads = 256 * waves_per_simd;   // one workgroup on one CU: waves_per_simd waves on each of its 4 SIMDs
+  unsigned long long h[16];
+  for (int rep = 0; rep < 2; ++rep) {
+    hipLaunchKernelGGL((k<V, S, LDS>), dim3(1), dim3(threads), 0, 0, iters, items, out, sink);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, out, 8 * 4 * waves_per_simd, hipMemcpyDeviceToHost);
+  }
+  unsigned long long mx = 0;
+  for (int w = 0; w < 4 * waves_per_simd; ++w) mx = h[w] > mx ? h[w] : mx;
+  const double mfma_cycles = (double)iters * items * 16 * 32 * waves_per_simd;   // per SIMD
+  printf("waves/SIMD %d  items %d  V %3d  S %3d  LDS %d : %8.0f cycles per step and wave, pipe busy %5.1f %%\n", waves_per_simd,
+         items, V, S, (int)LDS, (double)mx / iters, 100.0 * mfma_cycles / (double)mx);
+}
+
+int main() {
+  unsigned long long* out;
+  float* sink;
+  (void)hipMalloc(&out, 8 * 64);
+  (void)hipMalloc(&sink, 4 * 4096);
+  for (int w : {1, 2, 4}) {
+    run<0, 0, false>(w, 3, out, sink);
+    run<50, 0, false>(w, 3, out, sink);
+    run<50, 40, false>(w, 3, out, sink);
+    run<50, 40, true>(w, 3, out, sink);
+    run<100, 40, true>(w, 3, out, sink);
+  }
+  return 0;
+}
