@@ -74,6 +74,13 @@ __device__ unsigned long long pcc_stamp_buf[4096 * PCC_NSTAMP];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 
+// (k / div) % 3 for k = 0 .. 26 as 2-bit fields of one word
+__host__ __device__ constexpr uint64_t digits3(int div) {
+  uint64_t v = 0;
+  for (int k = 0; k < 27; ++k) v |= (uint64_t)((k / div) % 3) << (2 * k);
+  return v;
+}
+
 // weights [k_vol][32][cout] (ci major) -> [k_vol][cout / 32][64 lanes][16]: lane (m, q) of column half y:
 // s = 0..7: W[4s+q][32y + m], then W[4s+q][32y + 16 + m]
 __global__ __launch_bounds__(256) void k_conv16_swizzle(const float* __restrict__ w, int k_vol, int cout,
@@ -171,9 +178,12 @@ __global__ __launch_bounds__(64) void k_gconv16(
       // t = octant bit + step of the offset along an axis, in -1 .. 2: the parent-level offset is (t + 2) >> 1, the octant
       // bit of the neighbour inside that parent t & 1.  Per axis the three answers sit in one register (up_axis below)
       // and the offset's step selects a byte: three bit-field extracts and an add instead of a dozen instructions.
-      const uint32_t comb = __builtin_amdgcn_ubfe(up_x, 8u * (uint32_t)(kk / 9), 8u) +
-                            __builtin_amdgcn_ubfe(up_y, 8u * (uint32_t)((kk / 3) % 3), 8u) +
-                            __builtin_amdgcn_ubfe(up_z, 8u * (uint32_t)(kk % 3), 8u);
+      // digits of kk in base 3 from 2-bit fields of three constants (a shift and a mask instead of two divisions)
+      constexpr uint64_t DX = digits3(9), DY = digits3(3), DZ = digits3(1);
+      const uint32_t sh = 2u * (uint32_t)kk;
+      const uint32_t comb = __builtin_amdgcn_ubfe(up_x, ((uint32_t)(DX >> sh) & 3u) << 3, 8u) +
+                            __builtin_amdgcn_ubfe(up_y, ((uint32_t)(DY >> sh) & 3u) << 3, 8u) +
+                            __builtin_amdgcn_ubfe(up_z, ((uint32_t)(DZ >> sh) & 3u) << 3, 8u);
       const int kp = (int)(comb & 31u);
       nb_op = (int)(comb >> 5);
       if constexpr (WIDE) {
@@ -316,6 +326,8 @@ __global__ __launch_bounds__(64) void k_gconv16(
     // loads under a branch would make the compiler's s_waitcnt vmcnt counts inexact, and an inexact count in front
     // of an item's chains waits for the neighbour index and the weights requested at the top of this very step
     gather(0);
+    // (the tile read for item g+1 is unconditional: when the offset has no item g+1 its slots hold pad records, whose
+    // accumulator row is the sink row)
     // Item g >= 1: [write-back of item g-1 behind the first MFMA pair, tile of item g+1 requested] chains of item g;
     // the last item of the step writes itself back.  Items of one offset touch disjoint rows, so the order of these
     // LDS accesses inside a step is free; across steps program order keeps every write in front of the next read.
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
       LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
       HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv[0], HI, 0, 0, 0);                            \
       acc_write(rc_[(g) - 1], PLO, PHI);                                                               \
-      acc_read(more ? rc_[(g) + 1 < NI ? (g) + 1 : 0] : a_sink, PLO, PHI);                             \
+      if constexpr ((g) + 1 < NI) acc_read(rc_[(g) + 1 < NI ? (g) + 1 : 0], PLO, PHI);                 \
       _Pragma("unroll") for (int s = 1; s < 8; ++s) {                                                  \
         LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], LO, 0, 0, 0);                          \
         HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], HI, 0, 0, 0);                          \
