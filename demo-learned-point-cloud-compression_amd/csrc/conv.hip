@@ -372,24 +372,25 @@ static bool force_wide_rows() {
 template <bool HEAD, bool UP, bool PERM, int COUT, bool WIDE>
 static void launch16w(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch, int64_t n_out,
                       const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
-                      float* ho, const float* cw, const float* cb, float* co) {
+                      float* ho, const float* cw, const float* cb, float* co, uint32_t in_bytes) {
   if (n_out < kSmallLaunchRows)
     hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 32, WIDE>), dim3((nblk(n_out, 32) + 7) / 8 * 8, COUT / 32), dim3(64), 0,
-                       st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+                       st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, in_bytes);
   else
     hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 64, WIDE>), dim3((nblk(n_out, 64) + 7) / 8 * 8, COUT / 32), dim3(64), 0,
-                       st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+                       st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, in_bytes);
 }
 // n_in: rows of d_in (the byte offset of a row must fit 32 bits for the narrow form; UP: its parent book's pitch 24)
 template <bool HEAD, bool UP, bool PERM, int COUT>
 static void launch16(hipStream_t st, const float* d_in, int64_t n_in, const int32_t* d_nbr, int k_vol, int64_t pitch,
                      int64_t n_out, const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw,
                      const float* hb, float* ho, const float* cw = nullptr, const float* cb = nullptr, float* co = nullptr) {
-  const bool wide = n_in > ((int64_t)1 << 25) || (UP && pitch >= ((int64_t)1 << 24)) || force_wide_rows();
+  const bool wide = n_in >= ((int64_t)1 << 25) || (UP && pitch >= ((int64_t)1 << 24)) || force_wide_rows();
   if (wide)
-    launch16w<HEAD, UP, PERM, COUT, true>(st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
-  else
-    launch16w<HEAD, UP, PERM, COUT, false>(st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+    launch16w<HEAD, UP, PERM, COUT, true>(st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, 0u);
+  else   // n_in * 128 <= 2^32 - 128: the pad offset of conv16.h lies beyond the buffer
+    launch16w<HEAD, UP, PERM, COUT, false>(st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co,
+                                           (uint32_t)(n_in * 128));
 }
 
 static bool conv16_shape(const float* d_in, const float* d_out, int k_vol, int cin, int cout) {

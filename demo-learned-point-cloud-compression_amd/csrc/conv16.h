@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
     int64_t n_out, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
     float* __restrict__ out, const float* __restrict__ head_w, const float* __restrict__ head_b,
     float* __restrict__ head_out, const float* __restrict__ rgb_w = nullptr, const float* __restrict__ rgb_b = nullptr,
-    float* __restrict__ rgb_out = nullptr) {
+    float* __restrict__ rgb_out = nullptr, uint32_t in_bytes = 0u) {
   static_assert(R == 64 || R == 32, "window of 64 or 32 rows");
   // Accumulators in LDS: two planes (channels 0..15, 16..31) of 16-float rows; the 16-B piece q of a row sits at
   // position (q + 2 (row >> 2)) & 3 of its plane row.  The hardware serves a ds_read_b128 / ds_write_b128 in groups of 16
@@ -141,6 +141,11 @@ __global__ __launch_bounds__(64) void k_gconv16(
   auto acc_row = [](int row) -> int { return row * 64 + (((row >> 1) & 2) << 4); };
   const int a_own = acc_row(lane), a_sink = acc_row(R), q16 = q << 4;
   const uint32_t qoff = (uint32_t)q * 32u;   // bytes: channels 8q .. of an input row
+  // !WIDE: the rows are gathered with raw buffer loads over [in, in + in_bytes).  A pad slot's offset lies beyond the
+  // buffer: such a lane returns zeros without a fetch, and the gather of an item no row of the next offset needs (issued
+  // all the same, to keep the compiler's vmcnt counts exact) costs a quarter of a real one (tools/micro/mix.hip)
+  constexpr uint32_t kPadOff = 0xFFFFFF80u;
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00027000);
   {  // accumulators start at the bias: lane (grow, chunk) fills piece `chunk` (channels 4 chunk ..) of rows grow + 8 it
     const float* bp = bias + col0 + chunk * 4;
     const float4 b4 = make_float4(bp[0], bp[1], bp[2], bp[3]);
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
     const int cnt = __popcll(bal);
     const int32_t sx = WIDE ? src : (int32_t)((uint32_t)src << 7);
-    rec[b][p ? rank : cnt + lane - rank] = p ? make_int2(sx, a_own) : make_int2(0, a_sink);
+    rec[b][p ? rank : cnt + lane - rank] = p ? make_int2(sx, a_own) : make_int2(WIDE ? 0 : (int32_t)kPadOff, a_sink);
     return cnt;
   };
 
@@ -236,9 +241,11 @@ __global__ __launch_bounds__(64) void k_gconv16(
       G[g][0] = *reinterpret_cast<const float4*>(xr);
       G[g][1] = *reinterpret_cast<const float4*>(xr + 4);
     } else {
-      const char* xr = reinterpret_cast<const char*>(in) + ((uint32_t)rin[g] | qoff);
-      G[g][0] = *reinterpret_cast<const float4*>(xr);
-      G[g][1] = *reinterpret_cast<const float4*>(xr + 16);
+      const uint32_t off = (uint32_t)rin[g] | qoff;
+      const auto r0 = __builtin_amdgcn_raw_buffer_load_b128(in_rs, off, 0, 0);
+      const auto r1 = __builtin_amdgcn_raw_buffer_load_b128(in_rs, off + 16u, 0, 0);
+      G[g][0] = make_float4(__uint_as_float(r0[0]), __uint_as_float(r0[1]), __uint_as_float(r0[2]), __uint_as_float(r0[3]));
+      G[g][1] = make_float4(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r1[2]), __uint_as_float(r1[3]));
     }
   };
   auto acc_read = [&](int arow, f32x4& lo, f32x4& hi) {

@@ -7,7 +7,7 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int V, int S, bool LDS, int G = 0, int B = 0>
+template <int V, int S, bool LDS, int G = 0, int B = 0, int OOB = -1>
 __global__ void k(int iters, int items, unsigned long long* out, float* sink, const float4* __restrict__ gbuf = nullptr) {
   __shared__ __attribute__((aligned(16))) float tile[16][64 * 4 + 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -36,8 +36,18 @@ __global__ void k(int iters, int items, unsigned long long* out, float* sink, co
     if (G > 0) {   // G 16-byte loads per lane from a 64-KB buffer, consumed one step later (as the gathers and weights are)
 #pragma unroll
       for (int u = 0; u < G; ++u) { gsum.x += gq[u].x; }
+      if constexpr (OOB < 0) {
 #pragma unroll
-      for (int u = 0; u < G; ++u) gq[u] = gbuf[((i * 7 + u * 64 + lane) & 4095)];
+        for (int u = 0; u < G; ++u) gq[u] = gbuf[((i * 7 + u * 64 + lane) & 4095)];
+      } else {   // raw buffer loads; the first OOB of them beyond num_records (return zero, fetch nothing)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)gbuf, 0, 65536, 0x00027000);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const unsigned off = u < OOB ? 0x7FFF0000u : (unsigned)(((i * 7 + u * 64 + lane) & 4095) * 16);
+          const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+          gq[u] = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < B; ++u) {   // B data-dependent (never taken) scalar branches
@@ -53,21 +63,21 @@ __global__ void k(int iters, int items, unsigned long long* out, float* sink, co
   sink[blockIdx.x * blockDim.x + threadIdx.x] = lo[0] + hi[0] + (float)v + (float)sacc + gsum.x;
 }
 
-template <int V, int S, bool LDS, int G = 0, int B = 0>
+template <int V, int S, bool LDS, int G = 0, int B = 0, int OOB = -1>
 static void run(int waves_per_simd, int items, unsigned long long* out, float* sink, const float4* gbuf = nullptr) {
   const int iters = 4000;
   const int threads = 256 * waves_per_simd;   // one workgroup on one CU: waves_per_simd waves on each of its 4 SIMDs
   unsigned long long h[16];
   for (int rep = 0; rep < 2; ++rep) {
-    hipLaunchKernelGGL((k<V, S, LDS, G, B>), dim3(1), dim3(threads), 0, 0, iters, items, out, sink, gbuf);
+    hipLaunchKernelGGL((k<V, S, LDS, G, B, OOB>), dim3(1), dim3(threads), 0, 0, iters, items, out, sink, gbuf);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h, out, 8 * 4 * waves_per_simd, hipMemcpyDeviceToHost);
   }
   unsigned long long mx = 0;
   for (int w = 0; w < 4 * waves_per_simd; ++w) mx = h[w] > mx ? h[w] : mx;
   const double mfma_cycles = (double)iters * items * 16 * 32 * waves_per_simd;   // per SIMD
-  printf("waves/SIMD %d  items %d  V %3d  S %3d  LDS %d  G %2d  B %2d : %8.0f cycles per step and wave, pipe busy %5.1f %%\n", waves_per_simd,
-         items, V, S, (int)LDS, G, B, (double)mx / iters, 100.0 * mfma_cycles / (double)mx);
+  printf("waves/SIMD %d  items %d  V %3d  S %3d  LDS %d  G %2d  B %2d  OOB %2d : %8.0f cycles per step and wave, pipe busy %5.1f %%\n", waves_per_simd,
+         items, V, S, (int)LDS, G, B, OOB, (double)mx / iters, 100.0 * mfma_cycles / (double)mx);
 }
 
 int main() {
@@ -83,6 +93,9 @@ int main() {
     run<50, 40, true, 13, 10>(w, 3, out, sink, gbuf);
     run<50, 40, true, 0, 10>(w, 3, out, sink, gbuf);
     run<50, 40, true, 26, 10>(w, 3, out, sink, gbuf);
+    run<50, 40, true, 13, 10, 0>(w, 3, out, sink, gbuf);
+    run<50, 40, true, 13, 10, 3>(w, 3, out, sink, gbuf);
+    run<50, 40, true, 13, 10, 13>(w, 3, out, sink, gbuf);
   }
   for (int w : {4}) {
     run<0, 0, false>(w, 3, out, sink);
