@@ -36,28 +36,29 @@ __device__ __forceinline__ uint32_t ordered_key(float v) {
 // finished histograms (hist layout [pass][frame][256]): for each pass the digit d with
 //   (keys above d among the candidates) < k_rem <= (those + keys with digit d),
 // walking from the top digit down and stopping at d = 0 — k_topk_update's serial walk as a 256-lane suffix sum.
-// 256 threads; a few hundred cycles per pass, against one launch per pass saved.
+// The first 256 threads of the block do the walk (blocks of 256 or more threads; every thread gets the result); a few
+// hundred cycles per pass, against one launch per pass saved.
 __device__ __forceinline__ TopkState topk_state_after(TopkState s, const uint32_t* __restrict__ hist, int n_frames,
                                                       int f, int passes, uint32_t* lds /*[8]*/) {
   if (s.mode != 2) return s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (int p = 0; p < passes; ++p) {
-    const uint32_t c = hist[((size_t)p * n_frames + f) * 256 + (255 - t)];  // thread t holds digit 255 - t
+    const uint32_t c = t < 256 ? hist[((size_t)p * n_frames + f) * 256 + (255 - t)] : 0u;  // thread t holds digit 255 - t
     uint32_t inc = c;  // inclusive prefix over descending digits = keys with digit >= 255 - t
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t u = __shfl_up(inc, d, 64);
       if (lane >= d) inc += u;
     }
-    if (lane == 63) lds[wave] = inc;
+    if (lane == 63 && wave < 4) lds[wave] = inc;
     __syncthreads();
     uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += lds[w];
+    for (int w = 0; w < wave && w < 4; ++w) base += lds[w];
     inc += base;
     const uint32_t above = inc - c;  // keys with a larger digit
     const int digit = 255 - t;
     // the walk stops at the first digit (from the top) whose cumulative count reaches k_rem, but not below digit 1
-    const bool hit = digit >= 1 && above < s.k_rem && s.k_rem <= inc;
+    const bool hit = t < 256 && digit >= 1 && above < s.k_rem && s.k_rem <= inc;
     if (hit) { lds[4] = (uint32_t)digit; lds[5] = above; }
     if (t == 255) { lds[6] = above; }  // digit 0: everything above it
     __syncthreads();
@@ -76,7 +77,12 @@ __device__ __forceinline__ TopkState topk_state_after(TopkState s, const uint32_
 // (Closing a pass in the same launch — the last block of a frame to take a ticket walks the histogram — was
 // built and dropped: the device-scope fence each block needs before its ticket writes back its XCD's L2, 13 MB of
 // freshly written keys in pass 0: 64-97 us per pass instead of 5-23.)
-__global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ logits, uint32_t* __restrict__ keys,
+// Blocks of TKH_THREADS threads: the 256 counters of a block are merged into the frame's histogram with one global
+// atomic each, and same-address atomics serialise — with 1024 blocks of 256 threads that merge was 9 (top byte: a few
+// hot digits) and 18 us (second byte) of the 21 / 24 us of the first two passes over 3.26M keys; a quarter of the
+// blocks, a quarter of the merges.
+constexpr int TKH_THREADS = 1024;
+__global__ __launch_bounds__(TKH_THREADS) void k_topk_hist(const float* __restrict__ logits, uint32_t* __restrict__ keys,
                                                    const int64_t* __restrict__ offs,
                                                    const TopkState* __restrict__ state0, int pass,
                                                    uint32_t* __restrict__ hist, int n_frames) {
@@ -86,14 +92,14 @@ __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ log
   const int64_t lo = offs[f], hi = offs[f + 1];
   if (state0[f].mode != 2) return;  // nothing to select in this frame: its keys are never read (block-uniform)
   const TopkState s = topk_state_after(state0[f], hist, n_frames, f, pass, st_lds);
-  lh[threadIdx.x] = 0;
+  if (threadIdx.x < 256) lh[threadIdx.x] = 0;
   __syncthreads();
   const int shift = 24 - 8 * pass;
   const uint32_t himask = (pass == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
   // four independent loads in flight per thread: with one, a thread's dozen iterations each paid a full memory
   // latency in front of their LDS atomic (23-26 us for 3.26M keys, a 13-MB read)
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t r0 = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; r0 < hi; r0 += 4 * stride) {
+  const int64_t stride = (int64_t)gridDim.x * TKH_THREADS;
+  for (int64_t r0 = lo + (int64_t)blockIdx.x * TKH_THREADS + threadIdx.x; r0 < hi; r0 += 4 * stride) {
     uint32_t k[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -111,8 +117,10 @@ __global__ __launch_bounds__(256) void k_topk_hist(const float* __restrict__ log
     }
   }
   __syncthreads();
-  const uint32_t c = lh[threadIdx.x];
-  if (c) atomicAdd(&hist[((size_t)pass * n_frames + f) * 256 + threadIdx.x], c);
+  if (threadIdx.x < 256) {
+    const uint32_t c = lh[threadIdx.x];
+    if (c) atomicAdd(&hist[((size_t)pass * n_frames + f) * 256 + threadIdx.x], c);
+  }
 }
 
 // keep = every key above the threshold + the first k_rem keys equal to it in row order.  One flag array of 2n
@@ -339,8 +347,12 @@ extern "C" int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, in
   if (gx < 1) gx = 1;
   if (gx > 1024) gx = 1024;
   const dim3 grid2(gx, (unsigned)n_batch);
+  unsigned gxh = nblk(max_cnt, TKH_THREADS * 8);
+  if (gxh < 1) gxh = 1;
+  if (gxh > 256) gxh = 256;
+  const dim3 gridh(gxh, (unsigned)n_batch);
   for (int pass = 0; pass < 4; ++pass) {
-    hipLaunchKernelGGL(k_topk_hist, grid2, dim3(256), 0, st, d_logits, keys, (const int64_t*)offs,
+    hipLaunchKernelGGL(k_topk_hist, gridh, dim3(TKH_THREADS), 0, st, d_logits, keys, (const int64_t*)offs,
                        (const TopkState*)state, pass, hist, n_batch);
     PCC_CHECK_LAUNCH();
   }
