@@ -356,9 +356,10 @@ static int weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cout, cons
 }
 
 // one k_gconv16 launch.  Grid rounded up to a multiple of 8 workgroups: the kernel maps workgroup -> window per XCD.
-// Launches of fewer than kSmallLaunchRows rows (less than one round of 64-row windows on the chip's 4096 wave
-// slots) take 32-row windows: such a launch lasts as long as one window, and a 32-row window is the shorter one.
-constexpr int64_t kSmallLaunchRows = 200000;
+// Launches of fewer than kSmallLaunchRows rows (well under one round of 64-row windows on the chip's 4096 wave
+// slots) take 32-row windows: such a launch lasts as long as one window, and a 32-row window is the shorter one
+// (106k rows: 39 us on 64-row windows, 42 on 32-row ones; 26k rows: the other way round).
+constexpr int64_t kSmallLaunchRows = 100000;
 // PCC_CONV_WIDE_ROWS=1 in the environment (read once): every launch takes the 64-bit row arithmetic that tensors of
 // 2^25 rows and more need — how the tests reach that form without a 4-GB tensor.
 static bool force_wide_rows() {

@@ -439,7 +439,7 @@ def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
 
 @pytest.mark.parametrize("kind", ["dense", "dust"])
 def test_conv32_large_launch_bit_exact(rt, oracle, kind):
-    """launches of 200k rows and more run on 64-row windows (smaller ones on 32-row windows: the tests above): the same
+    """launches of 100k rows and more run on 64-row windows (smaller ones on 32-row windows: the tests above): the same
     entry points just past that size, a ragged last window included"""
     rng = np.random.default_rng(4242)
     n = 200_000 + 77
