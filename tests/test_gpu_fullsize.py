@@ -175,3 +175,37 @@ def test_c3_lidar_geometry_only(rt, oracle, wl):
     assert np.array_equal(np.unique(dec, axis=0), np.unique(pts, axis=0)) and dec.shape[0] == pts.shape[0]
     bpp = 8 * len(blob) / pts.shape[0]
     assert bpp < 16, bpp
+
+
+def test_conv_gathers_rows_beyond_two_gigabytes():
+    """k_gconv16 gathers its input rows with 32-bit byte offsets into a raw buffer over the tensor (conv16.h; tensors
+    of 2^25 rows = 4 GB and more take 64-bit arithmetic instead).  A 2.15-GB input (2^24 + 4096 rows) whose rule book
+    reaches rows on both sides of the 2-GB line, the last row included: the offsets above 2^31 and the buffer size are
+    unsigned quantities.  Centre offset only, identity weights: out = relu(x[nbr] + b) exactly (one fused multiply-add
+    by 1.0 per output), so the expected rows need no oracle run at this size."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rtm = pkg("runtime")
+    rt = rtm.Runtime(0)
+    with rt:
+        n_in, n_out = (1 << 24) + 4096, 250_000
+        g = torch.Generator(device="cuda").manual_seed(5)
+        x = torch.randn((n_in, 32), generator=g, device="cuda")
+        rows = (n_in - 1 - 67 * torch.arange(n_out, device="cuda", dtype=torch.int64)).to(torch.int32)   # 16.78M .. 31k
+        assert int(rows.min()) >= 0 and int(rows.max()) == n_in - 1 and int(rows.min()) * 128 < (1 << 31) < int(rows.max()) * 128
+        rows[::7] = -1                                                   # absent neighbours in between
+        nbr = torch.full((27, n_out), -1, dtype=torch.int32, device="cuda")
+        nbr[13] = rows
+        w = torch.zeros((27, 32, 32), device="cuda")
+        w[13] = torch.eye(32, device="cuda")
+        b = torch.randn((32,), generator=g, device="cuda")
+        got = rt.sparse_conv(x, nbr, w, b, True)
+        idx = rows.to(torch.int64).clamp(min=0)
+        want = torch.where((rows >= 0)[:, None], x[idx] + b, b.expand(n_out, 32)).clamp(min=0)
+        assert torch.equal(got, want)
+        hw = torch.randn((32, 1), generator=g, device="cuda")
+        hb = torch.zeros((1,), device="cuda")
+        got2, _ = rt.sparse_conv_head(x, nbr, w, b, True, hw, hb)
+        assert torch.equal(got2, want)
+        del x, got, got2, want
+    rt.close()
