@@ -97,6 +97,11 @@ int main() {
     run<50, 40, true, 13, 10, 3>(w, 3, out, sink, gbuf);
     run<50, 40, true, 13, 10, 13>(w, 3, out, sink, gbuf);
   }
+  // a 128-row window per wave (5 items, 21 loads, 18 branches per step) at two and three waves per SIMD
+  run<60, 45, true, 21, 18>(2, 5, out, sink, gbuf);
+  run<60, 45, true, 21, 18>(3, 5, out, sink, gbuf);
+  run<60, 45, true, 21, 18, 0>(2, 5, out, sink, gbuf);
+  run<50, 40, true, 13, 10, 0>(4, 3, out, sink, gbuf);
   for (int w : {4}) {
     run<0, 0, false>(w, 3, out, sink);
     run<50, 0, false>(w, 3, out, sink);
