@@ -696,6 +696,227 @@ __global__ __launch_bounds__(SS_THREADS) void k_compact_coord_keys(const int4* _
   }
 }
 
+// ---- the same canonical order over several workgroups (latents of CKM_MIN rows and more) --------------------------
+// One workgroup sweeps the rows three times with its own latency in front of every sweep (45 us for a 26k-row latent,
+// four times per GOP step).  Four launches of many workgroups instead, each a plain parallel pass:
+//   k_ckm_range : Morton key -> row (b, x, y, z), per-workgroup min / max / varying bits of every field; clears the bitmap
+//   k_ckm_bits  : compact key of every row, one bit per key in a global bitmap (a bit found set = a repeated row)
+//   k_ckm_scan  : one workgroup: occupied keys in front of every bitmap word
+//   k_ckm_place : perm[rank(key)] = row, ordered rows; or, when the domain is too wide / a row repeats, the compact
+//                 (or decimal) key of every row for k_sort_small, which is launched behind either way (`done`)
+// Every workgroup derives the field widths from the per-workgroup ranges for itself (ckm_params).
+constexpr int CKM_THREADS = 256;
+constexpr int CKM_ROWS = 1024;          // rows per workgroup
+constexpr int64_t CKM_MIN = 8192;       // below: the single-workgroup kernel (10-13 us at 2-3k rows)
+struct CkmPart { int mn[4], mx[4]; unsigned orv[4]; int bad; };
+struct CkmParams { int m[4], tz[4], w[4], total; bool compact; };
+
+__device__ __forceinline__ CkmParams ckm_params(const CkmPart* __restrict__ part, int n_part, int* lds /* [16] */) {
+  // n_part <= 64: one wave reduces the partial ranges, everybody reads the result
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    CkmPart p;
+    if (lane < n_part) p = part[lane];
+    else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { p.mn[f] = 0x7fffffff; p.mx[f] = (int)0x80000000; p.orv[f] = 0u; }
+      p.bad = 0;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        p.mn[f] = min(p.mn[f], __shfl_xor(p.mn[f], d, 64));
+        p.mx[f] = max(p.mx[f], __shfl_xor(p.mx[f], d, 64));
+        p.orv[f] |= (unsigned)__shfl_xor((int)p.orv[f], d, 64);
+      }
+    }
+    const int bad = __any(p.bad != 0) ? 1 : 0;
+    if (lane == 0) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) { lds[f] = p.mn[f]; lds[4 + f] = p.mx[f]; lds[8 + f] = (int)p.orv[f]; }
+      lds[12] = bad;
+    }
+  }
+  __syncthreads();
+  CkmParams q;
+  q.total = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const unsigned o = (unsigned)lds[8 + f];
+    q.m[f] = lds[f];
+    q.tz[f] = o ? __builtin_ctz(o) : 0;
+    const unsigned span = ((unsigned)(lds[4 + f] - lds[f])) >> q.tz[f];
+    q.w[f] = span ? 32 - __builtin_clz(span) : 0;
+    q.total += q.w[f];
+  }
+  q.compact = lds[12] == 0 && q.total <= 63;
+  return q;
+}
+__device__ __forceinline__ uint64_t ckm_key(const CkmParams& q, const int4 c) {
+  uint64_t k = (uint64_t)((unsigned)(c.x - q.m[0]) >> q.tz[0]);
+  k = (k << q.w[1]) | (uint64_t)((unsigned)(c.y - q.m[1]) >> q.tz[1]);
+  k = (k << q.w[2]) | (uint64_t)((unsigned)(c.z - q.m[2]) >> q.tz[2]);
+  k = (k << q.w[3]) | (uint64_t)((unsigned)(c.w - q.m[3]) >> q.tz[3]);
+  return k;
+}
+
+__global__ __launch_bounds__(CKM_THREADS) void k_ckm_range(const uint64_t* __restrict__ mkeys, int n, int4* __restrict__ coords,
+                                                           CkmPart* __restrict__ part, uint32_t* __restrict__ bitmap,
+                                                           int* __restrict__ flags /* [0] dup */) {
+  __shared__ int s_mn[4], s_mx[4], s_bad;
+  __shared__ unsigned s_or[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 4) { s_mn[tid] = 0x7fffffff; s_mx[tid] = (int)0x80000000; s_or[tid] = 0u; }
+  if (tid == 0) s_bad = 0;
+  if (blockIdx.x == 0 && tid == 0) flags[0] = 0;
+  // this workgroup's share of the 2^20-bit bitmap
+  const int words = (1 << CK_BITMAP_BITS) / 32, per = (words + gridDim.x - 1) / gridDim.x;
+  for (int j = blockIdx.x * per + tid; j < min((int)(blockIdx.x + 1) * per, words); j += CKM_THREADS) bitmap[j] = 0u;
+  __syncthreads();
+  int b0, x0, y0, z0;
+  pcc_unmorton(mkeys[0], &b0, &x0, &y0, &z0);
+  const int r[4] = {b0, x0, y0, z0};
+  int mn[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  int mx[4] = {(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  unsigned orv[4] = {0u, 0u, 0u, 0u};
+  bool bad = false;
+  const int e_lo = blockIdx.x * CKM_ROWS, e_hi = min(e_lo + CKM_ROWS, n);
+  for (int e = e_lo + tid; e < e_hi; e += CKM_THREADS) {
+    int b, x, y, z;
+    pcc_unmorton(mkeys[e], &b, &x, &y, &z);
+    coords[e] = make_int4(b, x, y, z);
+    const int v[4] = {b, x, y, z};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      mn[f] = min(mn[f], v[f]);
+      mx[f] = max(mx[f], v[f]);
+      orv[f] |= (unsigned)(v[f] ^ r[f]);
+    }
+    bad |= (b < 0) | (x <= -50000) | (x >= 50000) | (y <= -50000) | (y >= 50000) | (z <= -50000) | (z >= 50000);
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      mn[f] = min(mn[f], __shfl_xor(mn[f], d, 64));
+      mx[f] = max(mx[f], __shfl_xor(mx[f], d, 64));
+      orv[f] |= (unsigned)__shfl_xor((int)orv[f], d, 64);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { atomicMin(&s_mn[f], mn[f]); atomicMax(&s_mx[f], mx[f]); atomicOr(&s_or[f], orv[f]); }
+  }
+  if (__any(bad) && lane == 0) atomicOr(&s_bad, 1);
+  __syncthreads();
+  if (tid == 0) {
+    CkmPart p;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { p.mn[f] = s_mn[f]; p.mx[f] = s_mx[f]; p.orv[f] = s_or[f]; }
+    p.bad = s_bad;
+    part[blockIdx.x] = p;
+  }
+}
+
+__global__ __launch_bounds__(CKM_THREADS) void k_ckm_bits(const int4* __restrict__ coords, int n, const CkmPart* __restrict__ part,
+                                                          uint32_t* __restrict__ bitmap, int* __restrict__ flags) {
+  __shared__ int lds[16];
+  const CkmParams q = ckm_params(part, gridDim.x, lds);
+  if (!(q.compact && q.total <= CK_BITMAP_BITS)) return;   // block-uniform
+  const int e_lo = blockIdx.x * CKM_ROWS, e_hi = min(e_lo + CKM_ROWS, n);
+  bool dup = false;
+  for (int e = e_lo + threadIdx.x; e < e_hi; e += CKM_THREADS) {
+    const uint32_t k = (uint32_t)ckm_key(q, coords[e]);
+    const uint32_t bit = 1u << (k & 31u);
+    dup |= (atomicOr(&bitmap[k >> 5], bit) & bit) != 0u;
+  }
+  if (__any(dup) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+}
+
+// one workgroup of SS_THREADS: prefix[j] = occupied keys in the words in front of word j; *done = the order is made here.
+// Thread t holds words t, t + 1024, t + 2048, ... (coalesced loads, all requested at once and before the widths are
+// known: one memory round trip for the kernel).  Row i of 1024 consecutive words is scanned inside its 16 waves by
+// shuffles; the 16 wave totals of every row are scanned once, in word order, by the first wave.  No large LDS array: a
+// workgroup with a 128-KB bitmap image in LDS took 16 us here whatever it did, this one takes a plain launch.
+__global__ __launch_bounds__(SS_THREADS) void k_ckm_scan(const CkmPart* __restrict__ part, int n_part,
+                                                         const uint32_t* __restrict__ bitmap, uint32_t* __restrict__ prefix,
+                                                         const int* __restrict__ flags, int* __restrict__ done) {
+  constexpr int kPer = (1 << CK_BITMAP_BITS) / 32 / SS_THREADS;   // rows of 1024 words: 32
+  __shared__ int lds[16];
+  __shared__ uint32_t s_tot[kPer * SS_WAVES];   // totals of (row, wave), row-major = word order
+  uint32_t pc[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) pc[i] = (uint32_t)__popc(bitmap[threadIdx.x + i * SS_THREADS]);
+  const int dup = flags[0];
+  const CkmParams q = ckm_params(part, n_part, lds);
+  const bool ok = q.compact && q.total <= CK_BITMAP_BITS && dup == 0;
+  if (threadIdx.x == 0) *done = ok ? 1 : 0;
+  if (!ok) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwords = max((1 << q.total) >> 5, 1);
+  const int rows = (nwords + SS_THREADS - 1) / SS_THREADS;   // block-uniform
+  uint32_t ex[kPer];   // exclusive count inside the wave
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    if (i < rows) {
+      const uint32_t c = tid + i * SS_THREADS < nwords ? pc[i] : 0u;
+      uint32_t inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+      }
+      ex[i] = inc - c;
+      if (lane == 63) s_tot[i * SS_WAVES + wave] = inc;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {   // exclusive scan of the rows * 16 totals, 64 at a time
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < rows * SS_WAVES; b0 += 64) {
+      const uint32_t c = s_tot[b0 + lane];
+      uint32_t inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+      }
+      s_tot[b0 + lane] = carry + inc - c;
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPer; ++i)
+    if (i < rows && tid + i * SS_THREADS < nwords) prefix[tid + i * SS_THREADS] = s_tot[i * SS_WAVES + wave] + ex[i];
+}
+
+__global__ __launch_bounds__(CKM_THREADS) void k_ckm_place(const int4* __restrict__ coords, int n, const CkmPart* __restrict__ part,
+                                                           const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
+                                                           const int* __restrict__ done, uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ perm, int4* __restrict__ sorted_out) {
+  __shared__ int lds[16];
+  const CkmParams q = ckm_params(part, gridDim.x, lds);
+  const bool placed = *done != 0;
+  const int e_lo = blockIdx.x * CKM_ROWS, e_hi = min(e_lo + CKM_ROWS, n);
+  for (int e = e_lo + threadIdx.x; e < e_hi; e += CKM_THREADS) {
+    const int4 c = coords[e];
+    if (placed) {
+      const uint32_t k = (uint32_t)ckm_key(q, c);
+      const uint32_t r = prefix[k >> 5] + (uint32_t)__popc(bitmap[k >> 5] & ((1u << (k & 31u)) - 1u));
+      perm[r] = (uint32_t)e;
+      if (sorted_out) sorted_out[r] = c;
+    } else if (q.compact) {
+      keys[e] = ckm_key(q, c);
+    } else {
+      const int64_t lin = (int64_t)c.x * 1000000000000000ll + (int64_t)c.y * 10000000000ll + (int64_t)c.z * 100000ll +
+                          (int64_t)c.w;
+      keys[e] = (uint64_t)lin ^ (1ull << 63);
+    }
+  }
+}
+
 extern "C" int pcc_sort_coords(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
                                uint32_t* d_perm) {
   PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_perm)), PCC_E_ARG, "pcc_sort_coords: null arg");
@@ -726,12 +947,34 @@ int64_t pcc_sort_small_max() { return SS_MAX; }
 int pcc_sort_keys_canonical(pcc_ctx* ctx, const uint64_t* d_mkeys, int64_t n, uint32_t* d_perm, int32_t* d_sorted_coords) {
   PCC_REQUIRE(ctx && d_mkeys && d_perm && d_sorted_coords && n >= 1 && n <= SS_MAX, PCC_E_ARG,
               "pcc_sort_keys_canonical: bad argument (n=%lld)", (long long)n);
-  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n) + pcc_align((size_t)n * 8) + pcc_align((size_t)n * 16) + 256));
+  PCC_TRY(pcc_arena_reserve(ctx, sort_scratch_bytes(n) + pcc_align((size_t)n * 8) + pcc_align((size_t)n * 16) + 256 +
+                                     2 * pcc_align((size_t)(1 << CK_BITMAP_BITS) / 8) + pcc_align(sizeof(CkmPart) * 64) + 512));
   int64_t* lk = (int64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
   int4* c = (int4*)pcc_arena_alloc(ctx, (size_t)n * 16);
   int* done = (int*)pcc_arena_alloc(ctx, 4);
   if (!lk || !c || !done) return PCC_E_NOMEM;
   PccProfScope prof(ctx, "sort_coords", n, 0, 0, 0);
+  if (n >= CKM_MIN) {
+    const int nb = (int)nblk(n, CKM_ROWS);   // <= 64 (n <= SS_MAX)
+    CkmPart* part = (CkmPart*)pcc_arena_alloc(ctx, sizeof(CkmPart) * 64);
+    uint32_t* bitmap = (uint32_t*)pcc_arena_alloc(ctx, (size_t)(1 << CK_BITMAP_BITS) / 8);
+    uint32_t* prefix = (uint32_t*)pcc_arena_alloc(ctx, (size_t)(1 << CK_BITMAP_BITS) / 8);
+    int* flags = (int*)pcc_arena_alloc(ctx, 16);
+    if (!part || !bitmap || !prefix || !flags) return PCC_E_NOMEM;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_ckm_range, dim3(nb), dim3(CKM_THREADS), 0, st, d_mkeys, (int)n, c, part, bitmap, flags);
+    PCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ckm_bits, dim3(nb), dim3(CKM_THREADS), 0, st, (const int4*)c, (int)n, (const CkmPart*)part, bitmap, flags);
+    PCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ckm_scan, dim3(1), dim3(SS_THREADS), 0, st, (const CkmPart*)part, nb, (const uint32_t*)bitmap, prefix,
+                       (const int*)flags, done);
+    PCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ckm_place, dim3(nb), dim3(CKM_THREADS), 0, st, (const int4*)c, (int)n, (const CkmPart*)part,
+                       (const uint32_t*)bitmap, (const uint32_t*)prefix, (const int*)done, (uint64_t*)lk, d_perm,
+                       (int4*)d_sorted_coords);
+    PCC_CHECK_LAUNCH();
+    return sort_pairs_impl(ctx, (uint64_t*)lk, d_perm, n, 0, done, (const int4*)c, (int4*)d_sorted_coords);
+  }
   hipLaunchKernelGGL(k_keys_to_coords, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, d_mkeys, n, c);
   PCC_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_compact_coord_keys, dim3(1), dim3(SS_THREADS), 0, ctx->stream, (const int4*)c, (int)n, (uint64_t*)lk,
