@@ -42,6 +42,9 @@ def main():
         pad[:, :n] = present
         cnt = pad.view(27, nw, 64).sum(2)
         items = ((cnt + 15) // 16).clamp(min=1).sum(0).to(torch.float64)   # item 0 of an offset always runs
+        empty = (cnt == 0).sum().item()
+        print(f"(window, offset) pairs without a present row: {empty} of {27 * nw} ({100.0 * empty / (27 * nw):.2f} %): their item 0 "
+              f"runs on pad slots; slots issued / pairs = {16 * items.sum().item() / present.sum().item():.3f}")
         wpx = (nw + 7) // 8
         print(f"rows {n}, windows {nw}, pairs/row {per_row.mean().item():.2f}, items/window {items.mean().item():.2f}")
         for e in range(8):
