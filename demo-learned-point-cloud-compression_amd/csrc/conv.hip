@@ -33,6 +33,7 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 #endif
 
 #include "conv16.h"
+#include "convup.h"
 
 // The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound (252 MB: 108 MB of rule book, 128 MB of output).
 // One wave per 32-row tile, the product computed transposed (D[co][row] = W^T X^T) so that a lane ends up with 16
@@ -110,15 +111,18 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
 __global__ __launch_bounds__(256) void k_gconv_scalar(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int cin, int cout,
-    int relu, float* __restrict__ out) {
+    int relu, float* __restrict__ out, int sib) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / cout;
   const int co = (int)(t - row * cout);
   if (row >= n_out) return;
   float acc = bias[co];
+  // sib: siblings first (pcc.h) — the neighbours inside the row's own block of 8 rows, then the others
+  for (int pass = sib ? 0 : 1; pass < 2; ++pass)
   for (int k = 0; k < k_vol; ++k) {
     const int32_t nb = nbr[(int64_t)k * pitch + row];
     if (nb < 0) continue;
+    if (sib && (((int64_t)nb >> 3) == (row >> 3)) != (pass == 0)) continue;
     const float* x = in + (int64_t)nb * cin;
     const float* wk = w + ((int64_t)k * cin) * cout + co;
     for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], wk[(int64_t)ci * cout], acc);
@@ -394,14 +398,39 @@ static void launch16(hipStream_t st, const float* d_in, int64_t n_in, const int3
                                            (uint32_t)(n_in * 128));
 }
 
+// PCC_CONV_UP_LEGACY=1 in the environment (read once): the g_s layers stay on k_gconv16's UP form (two passes over the
+// offsets) instead of k_gconv_up — the cross-check of the two kernels and the form tensors of 2^25 rows and more take
+static bool force_up_legacy() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PCC_CONV_UP_LEGACY");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+// one g_s layer on the 8 n_parents children of a level: k_gconv_up (convup.h) when the byte offset of an input row fits
+// 32 bits and the parent book's pitch 24, else k_gconv16's UP form
+template <bool PERM>
+static void launch_up(hipStream_t st, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent, int64_t pitch,
+                      const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
+                      float* ho, const float* cw, const float* cb, float* co) {
+  const int64_t n_out = 8 * n_parents;
+  if (n_out < ((int64_t)1 << 25) && pitch < ((int64_t)1 << 24) && !force_wide_rows() && !force_up_legacy()) {
+    hipLaunchKernelGGL((k_gconv_up<PERM>), dim3((nblk(n_parents, 16) + 7) / 8 * 8), dim3(64), 0, st, d_in, d_nbr_parent, pitch,
+                       n_parents, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, (uint32_t)(n_out * 128));
+  } else {
+    launch16<true, true, PERM, 32>(st, d_in, n_out, d_nbr_parent, 27, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
+  }
+}
+
 static bool conv16_shape(const float* d_in, const float* d_out, int k_vol, int cin, int cout) {
   return !force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 32 &&
          (cout == 32 || cout == 64) && (k_vol == 27 || k_vol == 8);
 }
 
-extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
-                               int k_vol, int64_t nbr_pitch, int64_t n_out, const float* d_w,
-                               const float* d_bias, int cin, int cout, int relu, float* d_out) {
+static int sparse_conv_impl(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
+                            int k_vol, int64_t nbr_pitch, int64_t n_out, const float* d_w,
+                            const float* d_bias, int cin, int cout, int relu, float* d_out, bool sib) {
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv: null ctx");
   PCC_REQUIRE(k_vol == 27 || k_vol == 8 || k_vol == 1, PCC_E_ARG, "pcc_sparse_conv: k_vol=%d", k_vol);
   PCC_REQUIRE(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, PCC_E_ARG,
@@ -413,7 +442,7 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
   hipStream_t st = ctx->stream;
   const float* nof = nullptr;
   float* nofo = nullptr;
-  if (conv16_shape(d_in, d_out, k_vol, cin, cout)) {
+  if (!sib && conv16_shape(d_in, d_out, k_vol, cin, cout)) {
     const float* wsw;
     PCC_TRY(weights_for(ctx, d_w, k_vol, cout, &wsw));
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
@@ -421,17 +450,23 @@ extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, co
       launch16<false, false, false, 32>(st, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
     else
       launch16<false, false, false, 64>(st, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
-  } else if (!force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 && cout == 32) {
+  } else if (!sib && !force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 && cout == 32) {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
     hipLaunchKernelGGL(k_gconv_first, dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
                        nbr_pitch, n_out, d_w, d_bias, relu, d_out);
   } else {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
     hipLaunchKernelGGL(k_gconv_scalar, dim3(nblk(n_out * cout, 256)), dim3(256), 0, st, d_in, d_nbr,
-                       k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out);
+                       k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out, sib ? 1 : 0);
   }
   PCC_CHECK_LAUNCH();
   return PCC_OK;
+}
+
+extern "C" int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
+                               int k_vol, int64_t nbr_pitch, int64_t n_out, const float* d_w,
+                               const float* d_bias, int cin, int cout, int relu, float* d_out) {
+  return sparse_conv_impl(ctx, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out, false);
 }
 
 extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in, const int32_t* d_nbr,
@@ -450,8 +485,8 @@ extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_i
     PCC_CHECK_LAUNCH();
     return PCC_OK;
   }
-  // generic shapes: the two layers one after the other (same bits)
-  PCC_TRY(pcc_sparse_conv(ctx, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out));
+  // generic shapes: the two layers one after the other (same bits; the conv on the scalar kernel, siblings first)
+  PCC_TRY(sparse_conv_impl(ctx, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, cin, cout, relu, d_out, true));
   return pcc_linear(ctx, d_out, n_out, d_head_w, d_head_b, cout, 1, 0, d_head_out);
 }
 
@@ -474,11 +509,11 @@ static int head_up_impl(pcc_ctx* ctx, const float* d_in, int64_t n_parents, cons
   PCC_TRY(weights_for(ctx, d_w, 27, 32, &wsw));
   PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
   if (in_perm)
-    launch16<true, true, true, 32>(ctx->stream, d_in, n_out, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out,
-                                   d_head_w, d_head_b, d_head_out);
+    launch_up<true>(ctx->stream, d_in, n_parents, d_nbr_parent, parent_pitch, wsw, d_bias, relu, d_out, d_head_w, d_head_b,
+                    d_head_out, nullptr, nullptr, nullptr);
   else
-    launch16<true, true, false, 32>(ctx->stream, d_in, n_out, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, d_out,
-                                    d_head_w, d_head_b, d_head_out);
+    launch_up<false>(ctx->stream, d_in, n_parents, d_nbr_parent, parent_pitch, wsw, d_bias, relu, d_out, d_head_w, d_head_b,
+                     d_head_out, nullptr, nullptr, nullptr);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }
@@ -518,8 +553,8 @@ int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_
   const float* wsw;
   PCC_TRY(weights_for(ctx, d_w, 27, 32, &wsw));
   PccProfScope prof(ctx, "sparse_conv", n_out, 32, 32, 27);
-  launch16<true, true, true, 32>(ctx->stream, d_in, n_out, d_nbr_parent, 27, parent_pitch, n_out, wsw, d_bias, relu, nullptr,
-                                 d_head_w, d_head_b, d_head_out, d_rgb_w, d_rgb_b, d_rgb_out);
+  launch_up<true>(ctx->stream, d_in, n_parents, d_nbr_parent, parent_pitch, wsw, d_bias, relu, nullptr, d_head_w, d_head_b,
+                  d_head_out, d_rgb_w, d_rgb_b, d_rgb_out);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -31,6 +31,12 @@
 // stages that way (permuted weight columns, codec.hip).  Natural layout (PERM = false): lane (n, q) reads channels
 // 8q .. 8q+7 and the four q-lanes of a slot transpose two 4 x 4 blocks with v_permlane32_swap / v_permlane16_swap.
 //
+// HEAD (the conv3 + occupancy head layers of g_s): the neighbours are visited SIBLINGS FIRST (include/pcc.h) — here as two
+// passes over the offsets, the first taking the neighbours inside the output row's own block of 8 rows (UP: the
+// offsets that stay inside the row's parent), the second the others.  The shipped decoder runs these layers on
+// k_gconv_up (convup.h), which contracts the sibling pass as a dense product; this form serves explicit rule books
+// (pcc_sparse_conv_head) and tensors beyond k_gconv_up's 32-bit offsets.
+//
 // COUT = 64: a 32 -> 64 layer runs as grid.y = 2, workgroup (x, y) producing columns [32 y, 32 y + 32) of window x
 // (the h_s output layer, evaluated at the latent's rows only).
 //
@@ -173,12 +179,18 @@ __global__ __launch_bounds__(64) void k_gconv16(
   };
   const int oct = (int)(rc & 7);
   const uint32_t up_x = up_axis((oct >> 2) & 1, 9, 4), up_y = up_axis((oct >> 1) & 1, 3, 2), up_z = up_axis(oct & 1, 1, 1);
+  constexpr bool SIB = HEAD;   // siblings-first order: offsets 0 .. k_vol-1 twice (virtual offsets 0 .. 2 k_vol - 1)
+  const int kv_tot = SIB ? 2 * k_vol : k_vol;
   int32_t nb_raw = -1;   // UP: row of the parent-level neighbour; else the neighbour row itself
   int nb_op = 0;         // UP: octant of the neighbour inside that parent
   bool nb_live = false;  // offset exists and the lane owns a row
+  bool nb_first = true;  // SIB: the request belongs to the sibling pass
+  bool nb_own = false;   // SIB && UP: the offset stays inside the row's parent
   auto request_nb = [&](int k) {
-    const int kk = k < k_vol ? k : k_vol - 1;
-    nb_live = k < k_vol && row_ok;
+    const int kc = k < kv_tot ? k : kv_tot - 1;
+    nb_first = !SIB || kc < k_vol;
+    const int kk = nb_first ? kc : kc - k_vol;
+    nb_live = k < kv_tot && row_ok;
     if constexpr (UP) {
       // t = octant bit + step of the offset along an axis, in -1 .. 2: the parent-level offset is (t + 2) >> 1, the octant
       // bit of the neighbour inside that parent t & 1.  Per axis the three answers sit in one register (up_axis below)
@@ -191,6 +203,7 @@ __global__ __launch_bounds__(64) void k_gconv16(
                             __builtin_amdgcn_ubfe(up_z, ((uint32_t)(DZ >> sh) & 3u) << 3, 8u);
       const int kp = (int)(comb & 31u);
       nb_op = (int)(comb >> 5);
+      nb_own = kp == 13;
       if constexpr (WIDE) {
         nb_raw = nbr[(int64_t)kp * pitch + (rc >> 3)];
       } else {
@@ -206,7 +219,8 @@ __global__ __launch_bounds__(64) void k_gconv16(
   // exactly one record (no divergent branch): a present row the record of its rank, an absent one a pad record (row 0 of
   // `in`, accumulated into the sink row) in slot count + number of absent lanes in front of it
   auto compact = [&](int b) -> int {
-    const bool p = nb_live && nb_raw >= 0;
+    bool p = nb_live && nb_raw >= 0;
+    if constexpr (SIB) p = p && ((UP ? nb_own : (nb_raw >> 3) == (int32_t)rc3) == nb_first);
     const int32_t src = UP ? ((nb_raw << 3) | nb_op) : nb_raw;
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
@@ -221,7 +235,8 @@ __global__ __launch_bounds__(64) void k_gconv16(
   int rin[NI], ra0[NI], ra1[NI];  // input rows of the next offset's slots; accumulator rows (byte offsets) even / odd
   const uint32_t lane64 = (uint32_t)lane * 64u;
   auto load_w = [&](float4 (&W)[4], int k) {
-    const int kk = k < k_vol ? k : k_vol - 1;
+    const int kc = k < kv_tot ? k : kv_tot - 1;
+    const int kk = (SIB && kc >= k_vol) ? kc - k_vol : kc;
     const char* base = reinterpret_cast<const char*>(wsw + ((int64_t)kk * ny + ycol) * 1024);   // uniform
     const float4* p = reinterpret_cast<const float4*>(base + lane64);
 #pragma unroll
@@ -376,9 +391,9 @@ __global__ __launch_bounds__(64) void k_gconv16(
 #if PCC_CONV_STAMP
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-  for (int k = 0; k < k_vol; k += 2) {
+  for (int k = 0; k < kv_tot; k += 2) {
     step(k, W0, W1, ra0, ra1);
-    if (k + 1 < k_vol) step(k + 1, W1, W0, ra1, ra0);
+    if (k + 1 < kv_tot) step(k + 1, W1, W0, ra1, ra0);
   }
   PCC16_SYNC();
 #if PCC_CONV_STAMP

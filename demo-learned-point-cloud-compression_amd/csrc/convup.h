@@ -1,0 +1,378 @@
+// convup.h — the conv3 + occupancy head (+ colour head) layer of a g_s stage (receiver/decoder/codec_parallel.py:469),
+// 32 -> 32 channels, on the 8 N generative children of a level, given only THAT level's 27-offset rule book
+// (included by conv.hip after conv16.h, whose operand order of the weights and whose helpers it shares).
+//
+// On a generative level every parent has all of its 8 children, so the 27 neighbours of child row 8p + o fall in two
+// classes that the arithmetic contract (include/pcc.h, "siblings first") visits one after the other:
+//
+//   1. the 8 SIBLINGS (offsets that stay inside parent p, the row itself included) always exist: 8 of the ~14 pairs of
+//      a row.  For 16 parents they are one dense product Y[16 x 256] = X[16 x 256] . Wbig[256 x 256], Wbig's (o', o)
+//      block being W[k(o' - o)]: no rule book, no ballot, no compaction, no pad slot, no accumulator traffic through
+//      LDS.  A wave holds X (16 parents x 8 children x 32 channels: 64 registers) and the 8 x 2 accumulator tiles
+//      (64 registers) and walks the 27 offsets once: offset k feeds the (8, 4, 2 or 1) octant pairs with o' - o = d(k),
+//      so each octant's chain sees its siblings o' ascending = k ascending, and the weights of an offset are loaded once
+//      per window (108 16-byte loads instead of 256).
+//   2. the neighbours under OTHER parents exist where the parent-level neighbour exists: the irregular remainder,
+//      handled like k_gconv16 (rows that have the offset packed into 16-slot items by ballot + mbcnt, accumulators
+//      in LDS, everything requested one or two steps ahead) — but on a window of 128 rows = 16 parents with two rows per
+//      lane: one compaction step serves twice the rows (vector / scalar bookkeeping per row about halved; f32 MFMAs
+//      share the vector ALUs, DESIGN.md §4, so that is matrix time), and the lists of an offset are twice as long
+//      (issued / useful slots of the remainder 1.45 on 64-row windows, 1.22 on 128-row ones; the whole layer 1.10
+//      against k_gconv16's 1.18 on bench.py's dominant launch, simulated on its geometry).
+//
+// One wave per workgroup, no workgroup barrier.  LDS: 129 accumulator rows x 128 B + two record buffers = 19.5 KB:
+// eight waves per CU (two per SIMD), so registers are plentiful (__launch_bounds__(64, 2)).
+//
+// Offsets of the remainder: j = 0 .. 25 <-> k = j + (j >= 13) (the centre offset has no other-parent pair).  An octant
+// whose neighbour at offset k is a sibling sits that step out.  Up to 8 items per offset can occur (7 of 8 octants x 16
+// parents); four ride the software pipeline (records, gathered rows and accumulator tiles requested ahead), the rest —
+// windows in densely occupied regions — are contracted at the end of the step without prefetch.
+#pragma once
+
+template <bool PERM>
+__global__ __launch_bounds__(64, 2) void k_gconv_up(
+    const float* __restrict__ in, const int32_t* __restrict__ nbrp, int64_t pitch, int64_t n_par,
+    const float* __restrict__ wsw, const float* __restrict__ bias, int relu, float* __restrict__ out,
+    const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ head_out,
+    const float* __restrict__ rgb_w, const float* __restrict__ rgb_b, float* __restrict__ rgb_out, uint32_t in_bytes) {
+  constexpr int R = 128;             // rows of a window: 16 parents
+  constexpr int HP = (R + 1) * 16;   // floats per accumulator plane (row R = sink of the pad slots)
+  constexpr int NI = 4;              // pipelined items of an offset
+  constexpr int NJ = 26;             // offsets of the remainder
+  __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
+  // slot -> (byte offset of the input row, accumulator row address); behind a list of c records every lane writes one pad
+  // record (slots c .. c + 63), so the four pipelined items never meet a stale record
+  __shared__ __attribute__((aligned(8))) int2 rec[2][R + 64];
+
+  const int lane = threadIdx.x;
+  const int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware order (conv16.h)
+  const int64_t par0 = window * 16;
+  if (par0 >= n_par) return;
+  const int64_t row0 = par0 * 8, n_out = n_par * 8;
+  const int n = lane & 15, q = lane >> 4;
+  const int grow = lane >> 3, chunk = lane & 7;
+
+  auto acc_at = [&](int half, int row, int qq) -> int { return half * HP + row * 16 + (((qq + 2 * (row >> 2)) & 3) << 2); };
+  auto acc_row = [](int row) -> int { return row * 64 + (((row >> 1) & 2) << 4); };   // 4 * acc_at(0, row, qq) == acc_row(row) ^ (qq << 4)
+  const int a_own0 = acc_row(lane), a_own1 = acc_row(lane + 64), a_sink = acc_row(R), q16 = q << 4;
+  const uint32_t qoff = (uint32_t)q * 32u;
+  constexpr uint32_t kPadOff = 0xFFFFFF80u;   // beyond the buffer: the load returns zeros without a fetch
+  const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00027000);
+
+  auto load_w = [&](float4 (&W)[4], int k) {
+#ifdef PCCUP_ABL_W0    // timing ablation: four offsets' weights for all (L1-resident; the mask is 3 at run time, opaque at compile time)
+    k &= 3 + 28 * (int)(in_bytes >> 31);
+#endif
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wsw + (int64_t)k * 1024) + (uint32_t)lane * 64u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[j] = p[j];
+  };
+  auto load_row = [&](uint32_t off, float4& g0, float4& g1) {
+    const auto r0 = __builtin_amdgcn_raw_buffer_load_b128(in_rs, off, 0, 0);
+    const auto r1 = __builtin_amdgcn_raw_buffer_load_b128(in_rs, off + 16u, 0, 0);
+    g0 = make_float4(__uint_as_float(r0[0]), __uint_as_float(r0[1]), __uint_as_float(r0[2]), __uint_as_float(r0[3]));
+    g1 = make_float4(__uint_as_float(r1[0]), __uint_as_float(r1[1]), __uint_as_float(r1[2]), __uint_as_float(r1[3]));
+  };
+  // B operands in MFMA order from the two 16-B pieces lane (n, q) holds of its slot's row (conv16.h, PERM)
+  auto shape = [&](const float4& g0, const float4& g1, float (&xv)[8]) {
+    if constexpr (PERM) {
+      xv[0] = g0.x; xv[1] = g0.y; xv[2] = g0.z; xv[3] = g0.w;
+      xv[4] = g1.x; xv[5] = g1.y; xv[6] = g1.z; xv[7] = g1.w;
+    } else {
+      unsigned m[2][4] = {{__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)},
+                          {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)}};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x2 p = __builtin_amdgcn_permlane32_swap(m[b][0], m[b][2], false, false);
+        m[b][0] = p[0]; m[b][2] = p[1];
+        p = __builtin_amdgcn_permlane32_swap(m[b][1], m[b][3], false, false);
+        m[b][1] = p[0]; m[b][3] = p[1];
+        p = __builtin_amdgcn_permlane16_swap(m[b][0], m[b][1], false, false);
+        m[b][0] = p[0]; m[b][1] = p[1];
+        p = __builtin_amdgcn_permlane16_swap(m[b][2], m[b][3], false, false);
+        m[b][2] = p[0]; m[b][3] = p[1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xv[2 * t + b] = __uint_as_float(m[b][t]);
+      }
+    }
+  };
+  auto acc_read = [&](int arow, f32x4& lo, f32x4& hi) {
+    const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(acc_lds) + (arow ^ q16));
+    const float4 a = *reinterpret_cast<const float4*>(base);
+    const float4 b = *reinterpret_cast<const float4*>(base + HP);
+    lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; lo[3] = a.w;
+    hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; hi[3] = b.w;
+  };
+  auto acc_write = [&](int arow, const f32x4& lo, const f32x4& hi) {
+    float* base = reinterpret_cast<float*>(reinterpret_cast<char*>(acc_lds) + (arow ^ q16));
+    *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<float4*>(base + HP) = make_float4(hi[0], hi[1], hi[2], hi[3]);
+  };
+
+  // ---- remainder, first requests (their latency hides behind the sibling product): the two rows of lane l are
+  // children `oct` of parents par0 + (l >> 3) and par0 + 8 + (l >> 3)
+  const int oct = lane & 7;
+  const int64_t pa0 = par0 + (lane >> 3), pa1 = pa0 + 8;
+  const bool ok0 = pa0 < n_par, ok1 = pa1 < n_par;
+  const uint32_t pc0 = (uint32_t)(ok0 ? pa0 : n_par - 1), pc1 = (uint32_t)(ok1 ? pa1 : n_par - 1);
+  auto up_axis = [](int ob, int weight, int opbit) -> uint32_t {   // conv16.h: byte d = parent-offset digit * weight | octant bit << 5
+    uint32_t v = 0u;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int t = ob + d - 1;
+      v |= (uint32_t)((((t + 2) >> 1) * weight) | ((t & 1) ? (opbit << 5) : 0)) << (8 * d);
+    }
+    return v;
+  };
+  const uint32_t up_x = up_axis((oct >> 2) & 1, 9, 4), up_y = up_axis((oct >> 1) & 1, 3, 2), up_z = up_axis(oct & 1, 1, 1);
+  int32_t nb0 = -1, nb1 = -1;   // rows of the parent-level neighbours of the lane's two parents
+  uint32_t nb_op7 = 0u;         // octant of the neighbour inside that parent, << 7
+  bool nb_live = false;         // the offset exists and leaves the lane's parent
+  auto request_nb = [&](int j) {
+    const int jj = j < NJ ? j : NJ - 1;
+    const int kk = jj + (jj >= 13 ? 1 : 0);
+    constexpr uint64_t DX = digits3(9), DY = digits3(3), DZ = digits3(1);
+    const uint32_t sh = 2u * (uint32_t)kk;
+    const uint32_t comb = __builtin_amdgcn_ubfe(up_x, ((uint32_t)(DX >> sh) & 3u) << 3, 8u) +
+                          __builtin_amdgcn_ubfe(up_y, ((uint32_t)(DY >> sh) & 3u) << 3, 8u) +
+                          __builtin_amdgcn_ubfe(up_z, ((uint32_t)(DZ >> sh) & 3u) << 3, 8u);
+    const uint32_t kp = comb & 31u;
+    nb_op7 = (comb >> 5) << 7;
+    nb_live = j < NJ && kp != 13u;
+    const uint32_t base = __umul24(kp, (uint32_t)pitch);   // pitch < 2^24, 27 pitch < 2^30
+    nb0 = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(nbrp) + ((base + pc0) << 2));
+    nb1 = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(nbrp) + ((base + pc1) << 2));
+  };
+  // pack the rows that have the requested offset (under another parent) into slot records `b`; returns their count.
+  // Every lane also writes a pad record behind the list (input beyond the buffer, accumulated into the sink row).
+  auto compact = [&](int b) -> int {
+    const bool p0 = nb_live && ok0 && nb0 >= 0, p1 = nb_live && ok1 && nb1 >= 0;
+    const unsigned long long bal0 = __builtin_amdgcn_ballot_w64(p0), bal1 = __builtin_amdgcn_ballot_w64(p1);
+    const int c0 = __popcll(bal0), cnt = c0 + __popcll(bal1);
+    const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal0, 0u));
+    const int r1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal1, 0u));
+    rec[b][cnt + lane] = make_int2((int32_t)kPadOff, a_sink);
+    if (p0) rec[b][r0] = make_int2((int32_t)(((uint32_t)nb0 << 10) | nb_op7), a_own0);
+    if (p1) rec[b][r1] = make_int2((int32_t)(((uint32_t)nb1 << 10) | nb_op7), a_own1);
+    return cnt;
+  };
+  request_nb(0);
+
+  // ---- 1. siblings: dense product over the window's 16 parents (slot n = parent par0 + n)
+  {
+    float xs[8][8];
+    {
+      const int64_t pn = par0 + n;
+      const uint32_t rbase = pn < n_par ? (((uint32_t)pn << 10) | qoff) : kPadOff;   // child 0 of the slot's parent
+#pragma unroll
+      for (int op = 0; op < 8; ++op) {
+        float4 g0, g1;
+        load_row(pn < n_par ? rbase + ((uint32_t)op << 7) : kPadOff, g0, g1);
+        shape(g0, g1, xs[op]);
+      }
+    }
+    f32x4 lo[8], hi[8];
+    {
+      const float* bp = bias + 4 * q;
+      const f32x4 bl = {bp[0], bp[1], bp[2], bp[3]}, bh = {bp[16], bp[17], bp[18], bp[19]};
+#pragma unroll
+      for (int o = 0; o < 8; ++o) { lo[o] = bl; hi[o] = bh; }
+    }
+    // weights of an offset: one 4-KB block per wave from L2 (the 108 KB of a layer's weights do not fit the 32-KB L1).
+    // An offset's chains last 16 .. 128 MFMAs (0.25 .. 2 us); requested WD offsets ahead, and pinned there by the
+    // scheduling barriers, the blocks arrive behind matrix work instead of in front of it
+    constexpr int WD = 3;
+    float4 Wd[WD + 1][4];
+#pragma unroll
+    for (int k = 0; k < WD; ++k) load_w(Wd[k], k);
+#ifndef PCCUP_NO_DENSE   // timing ablations only (tools/ab_build.sh): wrong results
+#ifdef PCCUP_DENSE2
+    for (int rep = 0; rep < 2 + (int)(in_bytes >> 31); ++rep)
+#endif
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      if (k + WD < 27) load_w(Wd[(k + WD) % (WD + 1)], k + WD);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 (&Wc)[4] = Wd[k % (WD + 1)];
+      const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
+      const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
+      const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int tx = ((o >> 2) & 1) + dx, ty = ((o >> 1) & 1) + dy, tz = (o & 1) + dz;
+        if (tx < 0 || tx > 1 || ty < 0 || ty > 1 || tz < 0 || tz > 1) continue;   // the offset leaves the parent for this octant
+        const int op = tx * 4 + ty * 2 + tz;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          lo[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xs[op][s], lo[o], 0, 0, 0);
+          hi[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xs[op][s], hi[o], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    // the tiles seed the accumulators of the remainder: lane (n, q) holds channels 4q .. (+16) of row 8 n + o
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc_write(acc_row(8 * n + o), lo[o], hi[o]);
+    if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[acc_at(lane >> 2, R, lane & 3)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- 2. remainder
+  float4 G[NI][2];
+  float4 W0[4], W1[4];
+  int rin[NI], ra0[NI], ra1[NI];
+  auto load_wj = [&](float4 (&W)[4], int j) {
+    const int jj = j < NJ ? j : NJ - 1;
+    load_w(W, jj + (jj >= 13 ? 1 : 0));
+  };
+  auto read_records = [&](int b, int (&racc)[NI]) {
+#pragma unroll
+    for (int g = 0; g < NI; ++g) {
+      const int2 r = rec[b][g * 16 + n];
+      rin[g] = r.x;
+      racc[g] = r.y;
+    }
+  };
+#ifdef PCCUP_ABL_NEAR   // timing ablation: every gather from 1 MB of resident rows
+  auto gather = [&](int g) { load_row(((uint32_t)rin[g] & 0xFFF80u) | qoff, G[g][0], G[g][1]); };
+#else
+  auto gather = [&](int g) { load_row((uint32_t)rin[g] | qoff, G[g][0], G[g][1]); };
+#endif
+  int cnt_cur;
+  auto step = [&](int j, float4 (&Wc)[4], float4 (&Wn)[4], int (&rc_)[NI], int (&rn)[NI]) {
+    f32x4 lo0, hi0, lo1, hi1;
+    const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
+    const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
+    // item 0 is unconditional (pad slots into the sink row when the offset has no row) and carries the bookkeeping of
+    // the step between its MFMAs: one basic block (conv16.h)
+    acc_read(rc_[0], lo0, hi0);
+    acc_read(rc_[1], lo1, hi1);
+    float xv0[8];
+    shape(G[0][0], G[0][1], xv0);
+    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv0[0], lo0, 0, 0, 0);
+    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv0[0], hi0, 0, 0, 0);
+    const int cnt_next = compact((j + 1) & 1);
+    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[1], xv0[1], lo0, 0, 0, 0);
+    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[1], xv0[1], hi0, 0, 0, 0);
+    request_nb(j + 2);
+    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[2], xv0[2], lo0, 0, 0, 0);
+    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[2], xv0[2], hi0, 0, 0, 0);
+    load_wj(Wn, j + 1);
+    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[3], xv0[3], lo0, 0, 0, 0);
+    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[3], xv0[3], hi0, 0, 0, 0);
+    PCC16_SYNC();
+    read_records((j + 1) & 1, rn);
+#pragma unroll
+    for (int s = 4; s < 8; ++s) {
+      lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv0[s], lo0, 0, 0, 0);
+      hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
+    }
+    if (cnt_cur <= 16) acc_write(rc_[0], lo0, hi0);
+    gather(0);
+#define PCCUP_ITEM(g, LO, HI, PLO, PHI)                                                                \
+    if (cnt_cur > 16 * (g)) {                                                                          \
+      const bool more = (g) + 1 < NI && cnt_cur > 16 * ((g) + 1);                                      \
+      float xv[8];                                                                                     \
+      shape(G[g][0], G[g][1], xv);                                                                     \
+      LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
+      HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv[0], HI, 0, 0, 0);                            \
+      acc_write(rc_[(g) - 1], PLO, PHI);                                                               \
+      if constexpr ((g) + 1 < NI) acc_read(rc_[(g) + 1 < NI ? (g) + 1 : 0], PLO, PHI);                 \
+      _Pragma("unroll") for (int s = 1; s < 8; ++s) {                                                  \
+        LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], LO, 0, 0, 0);                          \
+        HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], HI, 0, 0, 0);                          \
+      }                                                                                                \
+      if (!more) acc_write(rc_[g], LO, HI);                                                            \
+    }                                                                                                  \
+    gather(g)
+    PCCUP_ITEM(1, lo1, hi1, lo0, hi0);
+    PCCUP_ITEM(2, lo0, hi0, lo1, hi1);
+    PCCUP_ITEM(3, lo1, hi1, lo0, hi0);
+#undef PCCUP_ITEM
+    // items beyond the pipeline (more than 64 rows of the window have the offset): record, rows, tile, chains, one by
+    // one.  The branch ends with nothing of its own in flight, so the counts of the prefetches above stay exact.
+    if (cnt_cur > 16 * NI) {
+      for (int g = NI; 16 * g < cnt_cur; ++g) {
+        const int2 r = rec[j & 1][g * 16 + n];
+        float4 g0, g1;
+        load_row((uint32_t)r.x | qoff, g0, g1);
+        f32x4 lo, hi;
+        acc_read(r.y, lo, hi);
+        float xv[8];
+        shape(g0, g1, xv);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
+          hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
+        }
+        acc_write(r.y, lo, hi);
+      }
+    }
+    cnt_cur = cnt_next;
+  };
+
+  // prologue of the remainder: offset 0 compacted and gathered, offset 1 requested
+  cnt_cur = compact(0);
+  request_nb(1);
+  load_wj(W0, 0);
+  PCC16_SYNC();
+  read_records(0, ra0);
+#pragma unroll
+  for (int g = 0; g < NI; ++g) gather(g);
+#ifndef PCCUP_NO_IRR
+  for (int j = 0; j < NJ; j += 2) {
+    step(j, W0, W1, ra0, ra1);
+    step(j + 1, W1, W0, ra1, ra0);
+  }
+#endif
+  PCC16_SYNC();
+
+#ifdef PCCUP_NO_EPI   // timing ablation: one word per lane instead of the epilogue
+  head_out[row0 + lane] = acc_lds[acc_at(0, lane, q)];
+  return;
+#endif
+  // ---- epilogue: the window's rows are contiguous in `out` (nullptr with the colour head: the last stage of g_s)
+  if (out != nullptr)
+#pragma unroll
+    for (int it = 0; it < R / 8; ++it) {
+      const int r = it * 8 + grow;
+      float4 v = *reinterpret_cast<const float4*>(&acc_lds[acc_at(chunk >> 2, r, chunk & 3)]);
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
+    }
+  // occupancy head (32 -> 1) and, at the last stage, the colour head (32 -> 3, no activation) of the lane's two rows:
+  // c ascending fmaf chains, the bits of pcc_linear on the stored rows
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = lane + 64 * h;
+    const int64_t gr = row0 + r;
+    float hv = head_b[0];
+    float cv[3] = {0.f, 0.f, 0.f};
+    if (rgb_out != nullptr) { cv[0] = rgb_b[0]; cv[1] = rgb_b[1]; cv[2] = rgb_b[2]; }
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(&acc_lds[acc_at(c4 >> 2, r, c4 & 3)]);
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = vv[j];
+        if (relu) v = fmaxf(v, 0.f);
+        hv = fmaf(v, head_w[4 * c4 + j], hv);
+        if (rgb_out != nullptr) {
+#pragma unroll
+          for (int o = 0; o < 3; ++o) cv[o] = fmaf(v, rgb_w[(4 * c4 + j) * 3 + o], cv[o]);
+        }
+      }
+    }
+    if (gr < n_out) {
+      head_out[gr] = hv;
+      if (rgb_out != nullptr) {
+        rgb_out[3 * gr] = cv[0];
+        rgb_out[3 * gr + 1] = cv[1];
+        rgb_out[3 * gr + 2] = cv[2];
+      }
+    }
+  }
+}

@@ -39,8 +39,16 @@
  * Arithmetic contract (what the parity tests check bit-for-bit)
  *   out[n][co] = bias[co]; for k ascending (present neighbours only), for ci
  *   ascending: out = fmaf(in[nbr[k][n]][ci], W[k][ci][co], out); then ReLU if
- *   asked.  Evaluated with v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf
- *   chain) or scalar fmaf; never atomics.
+ *   asked.  Evaluated with v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32
+ *   (exact k-ordered fmaf chains) or scalar fmaf; never atomics.
+ *   The conv3 + occupancy-head layers of g_s (pcc_sparse_conv_head*, which run
+ *   on the 8 N generative children of a level) visit the neighbours in
+ *   SIBLINGS-FIRST order: first those inside the output row's own aligned block
+ *   of 8 rows (nbr >> 3 == n >> 3: the children of the row's parent, itself
+ *   included), k ascending, then the others, k ascending.  MinkowskiEngine's
+ *   own order depends on atomics, so the order is this build's definition; it
+ *   makes a parent's 8 x 8 sibling pairs one dense register-resident product
+ *   (csrc/convup.h).  oracle/pcc_oracle.c states both orders.
  */
 #ifndef PCC_H
 #define PCC_H
@@ -220,9 +228,12 @@ int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
  * memory is freed or reused.  Shapes without such a form: PCC_E_ARG. */
 int pcc_conv_prepare(pcc_ctx* ctx, const float* d_w, int k_vol, int cin, int cout);
 int pcc_conv_forget(pcc_ctx* ctx, const float* d_w);
-/* the same layer with the 1x1 occupancy head of g_s fused into its epilogue:
- * d_head_out[n] = head_b[0] + sum_c fmaf(out[n][c], head_w[c]) (c ascending) —
- * bit-identical to pcc_linear(cout -> 1) applied to d_out, without re-reading it. */
+/* the conv3 layer of a g_s stage (codec_parallel.py:469) with the 1x1 occupancy
+ * head fused into its epilogue: d_head_out[n] = head_b[0] + sum_c fmaf(out[n][c],
+ * head_w[c]) (c ascending) — bit-identical to pcc_linear(cout -> 1) applied to
+ * d_out, without re-reading it.  Input and output rows are the same set (a
+ * generative level, n_in == n_out); neighbours are visited SIBLINGS FIRST (the
+ * arithmetic contract at the top of this file). */
 int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                          const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
                          int64_t n_out, const float* d_w, const float* d_bias,

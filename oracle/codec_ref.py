@@ -107,14 +107,16 @@ class Oracle:
         return rows
 
     # ------------------------------------------------------------ layers
-    def sparse_conv(self, x, nbr, w, b, relu):
+    def sparse_conv(self, x, nbr, w, b, relu, siblings_first=False):
+        """siblings_first: the accumulation order of g_s's conv3 layers (pcc_oracle.c, orc_sparse_conv)"""
         x = np.ascontiguousarray(x, dtype=np.float32)
         nbr = np.ascontiguousarray(nbr, dtype=np.int32)
         k, n_out = nbr.shape
         cin, cout = w.shape[1], w.shape[2]
         out = np.empty((n_out, cout), dtype=np.float32)
         self.lib.orc_sparse_conv(_p(x), _p(nbr), C.c_int(k), C.c_int64(n_out), C.c_int64(n_out), _p(w), _p(b),
-                                 C.c_int(cin), C.c_int(cout), C.c_int(int(relu)), _p(out))
+                                 C.c_int(cin), C.c_int(cout), C.c_int(int(relu)), C.c_int(int(siblings_first)),
+                                 _p(out))
         return out
 
     def convT(self, x, w, b, relu):
@@ -322,7 +324,7 @@ class Oracle:
             keys = self.up(keys, stride)
             stride //= 2
             offs = [8 * o for o in offs]
-            h = self.sparse_conv(h, self.map27(keys, stride), *self.wb(f"g_s.conv{j}"), True)
+            h = self.sparse_conv(h, self.map27(keys, stride), *self.wb(f"g_s.conv{j}"), True, siblings_first=True)
             w, b = self.wb(f"g_s.occ{j}")
             logits = self.linear(h, w, b)[:, 0]
             kj = [min(int(ks[j][f]), offs[f + 1] - offs[f]) for f in range(n_batch)]

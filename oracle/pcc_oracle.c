@@ -131,21 +131,33 @@ ORC_API void orc_lookup(const uint64_t* keys, int64_t n, const uint64_t* qkeys, 
 
 /* ----------------------------------------------------------------- layers */
 
+/* Accumulation order of a row (the arithmetic contract of include/pcc.h):
+ *   siblings_first == 0: k ascending over the present neighbours (every layer of g_a, h_a, h_s);
+ *   siblings_first != 0: first the neighbours that lie in the output row's own aligned block of 8 rows
+ *     (nb >> 3 == r >> 3: on a generative level the row's siblings under its parent, itself included), k ascending,
+ *     then all the others, k ascending — the conv3 layers of g_s, which run on the 8 N children of a level
+ *     (receiver/decoder/codec_parallel.py:469).  MinkowskiEngine's own order is scheduling-dependent (atomics), so the
+ *     order is this build's definition; it lets the HIP kernel contract a parent's 8 x 8 sibling pairs as one dense
+ *     register-resident product. */
 ORC_API void orc_sparse_conv(const float* in, const int32_t* nbr, int k_vol, int64_t pitch, int64_t n_out,
-                             const float* w, const float* bias, int cin, int cout, int relu, float* out) {
+                             const float* w, const float* bias, int cin, int cout, int relu, int siblings_first,
+                             float* out) {
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < n_out; ++r) {
     float acc[64];
     for (int co = 0; co < cout; ++co) acc[co] = bias[co];
-    for (int k = 0; k < k_vol; ++k) {
-      const int32_t nb = nbr[(int64_t)k * pitch + r];
-      if (nb < 0) continue;
-      const float* x = in + (int64_t)nb * cin;
-      const float* wk = w + (int64_t)k * cin * cout;
-      for (int ci = 0; ci < cin; ++ci) {
-        const float xv = x[ci];
-        const float* wr = wk + (int64_t)ci * cout;
-        for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+    for (int pass = siblings_first ? 0 : 1; pass < 2; ++pass) {
+      for (int k = 0; k < k_vol; ++k) {
+        const int32_t nb = nbr[(int64_t)k * pitch + r];
+        if (nb < 0) continue;
+        if (siblings_first && (((int64_t)nb >> 3) == (r >> 3)) != (pass == 0)) continue;
+        const float* x = in + (int64_t)nb * cin;
+        const float* wk = w + (int64_t)k * cin * cout;
+        for (int ci = 0; ci < cin; ++ci) {
+          const float xv = x[ci];
+          const float* wr = wk + (int64_t)ci * cout;
+          for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+        }
       }
     }
     for (int co = 0; co < cout; ++co) {

@@ -343,7 +343,7 @@ def test_sparse_conv_fused_head_bit_exact(rt, oracle, clouds, name, cin):
     hb = rng.normal(0, 0.1, 1).astype(np.float32)
     feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw),
                                         dev(rt, hb))
-    ref = oracle.sparse_conv(x, nbr, w, b, True)
+    ref = oracle.sparse_conv(x, nbr, w, b, True, siblings_first=True)      # the order of g_s's layers (include/pcc.h)
     assert np.array_equal(host(feats), ref)
     assert np.array_equal(host(logits), oracle.linear(ref, hw, hb)[:, 0])
 
@@ -388,7 +388,7 @@ def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
     assert np.array_equal(host(out), ref)
     feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw),
                                         dev(rt, hb))
-    refr = np.maximum(ref, 0)
+    refr = oracle.sparse_conv(x, nbr, w, b, True, siblings_first=True)
     assert np.array_equal(host(feats), refr)
     assert np.array_equal(host(logits), oracle.linear(refr, hw, hb)[:, 0])
     # the 32 -> 64 layer (the two column halves as grid.y) on the same neighbourhoods
@@ -398,11 +398,13 @@ def test_conv32_row_compaction_bit_exact(rt, oracle, kind, n):
 
 
 @pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
-@pytest.mark.parametrize("n", [1, 7, 8, 9, 63, 500, 2100])
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 15, 16, 17, 31, 33, 63, 500, 2100])
 def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
-    """pcc_sparse_conv_head_up: conv on the 8N generative children given only the parents' rule book, against
-    the oracle's conv over the hashed child rule book; pcc_subset_map_up: the rule book of a pruned subset of
-    those children against the oracle's hash build over the kept keys"""
+    """pcc_sparse_conv_head_up (k_gconv_up: windows of 16 parents, the siblings as a dense product, the other-parent
+    neighbours compacted per offset; `dense` clouds fill more than the four pipelined items of an offset): conv on the
+    8N generative children given only the parents' rule book, against the oracle's siblings-first conv over the hashed
+    child rule book; pcc_subset_map_up: the rule book of a pruned subset of those children against the oracle's hash
+    build over the kept keys"""
     rng = np.random.default_rng(77 + n)
     pts = _structured_cloud(kind, n) * 2
     pkeys = sorted_keys(oracle, pts)                       # stride-2 parents
@@ -413,7 +415,7 @@ def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
     w, b = _weights(rng, 27, 32, 32)
     hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
     hb = rng.normal(0, 0.1, 1).astype(np.float32)
-    ref = oracle.sparse_conv(x, nbr_c, w, b, True)
+    ref = oracle.sparse_conv(x, nbr_c, w, b, True, siblings_first=True)
     feats, logits = rt.sparse_conv_head_up(dev(rt, x), dev(rt, nbr_p), dev(rt, w), dev(rt, b), True, dev(rt, hw),
                                            dev(rt, hb))
     assert np.array_equal(host(feats), ref)
@@ -429,6 +431,9 @@ def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
                                              rtm._ptr(wd), rtm._ptr(bd), 1, rtm._ptr(f2), rtm._ptr(hwd),
                                              rtm._ptr(hbd), rtm._ptr(l2)), "pcc_sparse_conv_head_up")
     assert np.array_equal(host(f2), ref)
+    # the explicit child rule book gives the same bits (k_gconv16's two passes over the offsets)
+    f3, l3 = rt.sparse_conv_head(xd, dev(rt, nbr_c), wd, bd, True, hwd, hbd)
+    assert np.array_equal(host(f3), ref) and np.array_equal(host(l3), host(logits))
 
     keep = np.sort(rng.choice(len(ckeys), size=max(1, len(ckeys) // 3), replace=False)).astype(np.uint32)
     keep_d = dev(rt, keep.view(np.int32))
@@ -450,7 +455,7 @@ def test_conv32_large_launch_bit_exact(rt, oracle, kind):
     w, b = _weights(rng, 27, 32, 32)
     hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
     hb = rng.normal(0, 0.1, 1).astype(np.float32)
-    ref = oracle.sparse_conv(x, nbr, w, b, True)
+    ref = oracle.sparse_conv(x, nbr, w, b, True, siblings_first=True)
     feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw), dev(rt, hb))
     assert np.array_equal(host(feats), ref)
     assert np.array_equal(host(logits), oracle.linear(ref, hw, hb)[:, 0])
@@ -463,7 +468,7 @@ def test_conv32_large_launch_bit_exact(rt, oracle, kind):
     ckeys = oracle.up(pkeys, 2)
     assert len(ckeys) >= 200_000
     xc = rng.normal(size=(len(ckeys), 32)).astype(np.float32)
-    refc = oracle.sparse_conv(xc, oracle.map27(ckeys, 1), w, b, True)
+    refc = oracle.sparse_conv(xc, oracle.map27(ckeys, 1), w, b, True, siblings_first=True)
     fc, lc = rt.sparse_conv_head_up(dev(rt, xc), dev(rt, nbr_p), dev(rt, w), dev(rt, b), True, dev(rt, hw), dev(rt, hb))
     assert np.array_equal(host(fc), refc)
     assert np.array_equal(host(lc), oracle.linear(refc, hw, hb)[:, 0])
@@ -478,7 +483,19 @@ def test_conv_wide_row_form_is_bit_exact():
     import sys
     env = dict(os.environ, PCC_CONV_WIDE_ROWS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "conv and not switch and not wide_row"], env=env, capture_output=True, text=True, timeout=900)
+                        "-k", "conv and not switch and not wide_row and not legacy"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
+def test_conv_head_up_legacy_form_is_bit_exact():
+    """PCC_CONV_UP_LEGACY=1 (read once per process) keeps the g_s layers on k_gconv16's in-kernel-rule-book form (two
+    passes over the offsets: siblings, then the rest) instead of k_gconv_up — the form tensors of 2^25 rows and more
+    take: the head-up tests of this file once more under it, in a child process, against the same oracle results"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PCC_CONV_UP_LEGACY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "head_up_forms or large_launch"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
 
 
