@@ -20,7 +20,7 @@
 //      (issued / useful slots of the remainder 1.45 on 64-row windows, 1.22 on 128-row ones; the whole layer 1.10
 //      against k_gconv16's 1.18 on bench.py's dominant launch, simulated on its geometry).
 //
-// One wave per workgroup, no workgroup barrier.  LDS: 129 accumulator rows x 128 B + two record buffers = 19.5 KB:
+// One wave per workgroup, no workgroup barrier.  LDS: 129 accumulator rows x 128 B + two record buffers + book slice = 19.8 KB:
 // eight waves per CU (two per SIMD), so registers are plentiful (__launch_bounds__(64, 2)).
 //
 // Offsets of the remainder: j = 0 .. 25 <-> k = j + (j >= 13) (the centre offset has no other-parent pair).  An octant
@@ -40,10 +40,19 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   constexpr int NI = 4;              // pipelined items of an offset
   constexpr int NJ = 26;             // offsets of the remainder
   __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
-  // slot -> (byte offset of the input row, accumulator row address); behind a list of c records every lane writes one pad
-  // record (slots c .. c + 63), so the four pipelined items never meet a stale record
-  __shared__ __attribute__((aligned(8))) int2 rec[2][R + 64];
+  // slot -> (byte offset of the input row, accumulator row address): every lane writes the records of its two rows, a
+  // present row the record of its rank, an absent one a pad record behind the list — all R slots every step, no branch
+  __shared__ __attribute__((aligned(8))) int2 rec[2][R];
+  // the window's slice of the parent rule book, [27][16] (-1: no such parent or neighbour).  Fetched once, in front of the
+  // sibling product: the steps of the remainder then issue no load whose latency they cannot plan for — as two dword
+  // loads per step straight from the book (44 MB, streamed once: HBM latency) these sat in the in-order load queue in
+  // front of the gathers, and every step lasted one such latency (2.4k cycles for 0.5k - 2k cycles of matrix work)
+  __shared__ int32_t pb[27 * 16];
 
+#ifdef PCCUP_FAT_LDS   // diagnostic: one wave per SIMD (4 workgroups per CU)
+  __shared__ float fat_lds[5200];
+  if (in_bytes == 12345u) fat_lds[threadIdx.x] = 1.f;
+#endif
   const int lane = threadIdx.x;
   const int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware order (conv16.h)
   const int64_t par0 = window * 16;
@@ -97,6 +106,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     }
   };
   auto acc_read = [&](int arow, f32x4& lo, f32x4& hi) {
+#ifdef PCCUP_ABL_NOACC   // timing ablation: the remainder's tiles never come from LDS
+    if (arow != 0x7fffffff) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; return; }
+#endif
     const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(acc_lds) + (arow ^ q16));
     const float4 a = *reinterpret_cast<const float4*>(base);
     const float4 b = *reinterpret_cast<const float4*>(base + HP);
@@ -104,6 +116,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; hi[3] = b.w;
   };
   auto acc_write = [&](int arow, const f32x4& lo, const f32x4& hi) {
+#ifdef PCCUP_ABL_NOACC
+    if (arow != a_sink) { if (lo[0] == 1.2345f) acc_lds[0] = hi[0]; return; }
+#endif
     float* base = reinterpret_cast<float*>(reinterpret_cast<char*>(acc_lds) + (arow ^ q16));
     *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
     *reinterpret_cast<float4*>(base + HP) = make_float4(hi[0], hi[1], hi[2], hi[3]);
@@ -112,9 +127,14 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   // ---- remainder, first requests (their latency hides behind the sibling product): the two rows of lane l are
   // children `oct` of parents par0 + (l >> 3) and par0 + 8 + (l >> 3)
   const int oct = lane & 7;
-  const int64_t pa0 = par0 + (lane >> 3), pa1 = pa0 + 8;
-  const bool ok0 = pa0 < n_par, ok1 = pa1 < n_par;
-  const uint32_t pc0 = (uint32_t)(ok0 ? pa0 : n_par - 1), pc1 = (uint32_t)(ok1 ? pa1 : n_par - 1);
+  int32_t pbv[7];   // element e = lane + 64 i of the slice: offset e >> 4, parent e & 15
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int e = lane + 64 * i;
+    const int64_t pp = par0 + (e & 15);
+    pbv[i] = -1;
+    if (e < 27 * 16 && pp < n_par) pbv[i] = nbrp[(int64_t)(e >> 4) * pitch + pp];
+  }
   auto up_axis = [](int ob, int weight, int opbit) -> uint32_t {   // conv16.h: byte d = parent-offset digit * weight | octant bit << 5
     uint32_t v = 0u;
 #pragma unroll
@@ -139,24 +159,30 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     const uint32_t kp = comb & 31u;
     nb_op7 = (comb >> 5) << 7;
     nb_live = j < NJ && kp != 13u;
-    const uint32_t base = __umul24(kp, (uint32_t)pitch);   // pitch < 2^24, 27 pitch < 2^30
-    nb0 = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(nbrp) + ((base + pc0) << 2));
-    nb1 = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(nbrp) + ((base + pc1) << 2));
+    const int32_t* pr = pb + (kp << 4) + (lane >> 3);
+    nb0 = pr[0];
+    nb1 = pr[8];
   };
   // pack the rows that have the requested offset (under another parent) into slot records `b`; returns their count.
   // Every lane also writes a pad record behind the list (input beyond the buffer, accumulated into the sink row).
   auto compact = [&](int b) -> int {
-    const bool p0 = nb_live && ok0 && nb0 >= 0, p1 = nb_live && ok1 && nb1 >= 0;
+    const bool p0 = nb_live && nb0 >= 0, p1 = nb_live && nb1 >= 0;
     const unsigned long long bal0 = __builtin_amdgcn_ballot_w64(p0), bal1 = __builtin_amdgcn_ballot_w64(p1);
     const int c0 = __popcll(bal0), cnt = c0 + __popcll(bal1);
     const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal0, 0u));
-    const int r1 = c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal1, 0u));
-    rec[b][cnt + lane] = make_int2((int32_t)kPadOff, a_sink);
-    if (p0) rec[b][r0] = make_int2((int32_t)(((uint32_t)nb0 << 10) | nb_op7), a_own0);
-    if (p1) rec[b][r1] = make_int2((int32_t)(((uint32_t)nb1 << 10) | nb_op7), a_own1);
+    const int r1 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal1, 0u));
+    // present rows: ranks 0 .. cnt-1 (first rows, then second rows); absent ones: the pads cnt .. R-1 in the same order
+    const int s0 = p0 ? r0 : cnt + lane - r0;
+    const int s1 = p1 ? c0 + r1 : cnt + 64 - c0 + lane - r1;
+    rec[b][s0] = p0 ? make_int2((int32_t)(((uint32_t)nb0 << 10) | nb_op7), a_own0) : make_int2((int32_t)kPadOff, a_sink);
+    rec[b][s1] = p1 ? make_int2((int32_t)(((uint32_t)nb1 << 10) | nb_op7), a_own1) : make_int2((int32_t)kPadOff, a_sink);
     return cnt;
   };
-  request_nb(0);
+#if PCC_CONV_STAMP
+  unsigned long long st_sum[PCC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
 
   // ---- 1. siblings: dense product over the window's 16 parents (slot n = parent par0 + n)
   {
@@ -178,6 +204,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
 #pragma unroll
       for (int o = 0; o < 8; ++o) { lo[o] = bl; hi[o] = bh; }
     }
+    PCC_STAMP(0);   // issue of the X loads
     // weights of an offset: one 4-KB block per wave from L2 (the 108 KB of a layer's weights do not fit the 32-KB L1).
     // An offset's chains last 16 .. 128 MFMAs (0.25 .. 2 us); requested WD offsets ahead, and pinned there by the
     // scheduling barriers, the blocks arrive behind matrix work instead of in front of it
@@ -211,10 +238,17 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       __builtin_amdgcn_sched_barrier(0);
     }
 #endif
+    PCC_STAMP(2);   // sibling product
     // the tiles seed the accumulators of the remainder: lane (n, q) holds channels 4q .. (+16) of row 8 n + o
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc_write(acc_row(8 * n + o), lo[o], hi[o]);
     if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[acc_at(lane >> 2, R, lane & 3)]) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (lane + 64 * i < 27 * 16) pb[lane + 64 * i] = pbv[i];
+#ifdef PCCUP_FAT_LDS
+    if (in_bytes == 12345u) acc_lds[lane] = fat_lds[lane ^ 1];
+#endif
   }
 
   // ---- 2. remainder
@@ -233,13 +267,20 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       racc[g] = r.y;
     }
   };
-#ifdef PCCUP_ABL_NEAR   // timing ablation: every gather from 1 MB of resident rows
-  auto gather = [&](int g) { load_row(((uint32_t)rin[g] & 0xFFF80u) | qoff, G[g][0], G[g][1]); };
+#ifdef PCCUP_ABL_NEAR   // timing ablation: every gather from 16 KB of L1-resident rows
+  auto gather = [&](int g) { load_row(((uint32_t)rin[g] & 0x3F80u) | qoff, G[g][0], G[g][1]); };
 #else
   auto gather = [&](int g) { load_row((uint32_t)rin[g] | qoff, G[g][0], G[g][1]); };
 #endif
   int cnt_cur;
   auto step = [&](int j, float4 (&Wc)[4], float4 (&Wn)[4], int (&rc_)[NI], int (&rn)[NI]) {
+#if PCC_CONV_STAMP
+    unsigned long long tq[8];
+#define PCCUP_T(i) asm volatile("s_memtime %0" : "=s"(tq[i])::"memory")
+#else
+#define PCCUP_T(i) do { } while (0)
+#endif
+    PCCUP_T(0);
     f32x4 lo0, hi0, lo1, hi1;
     const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
     const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
@@ -251,15 +292,18 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     shape(G[0][0], G[0][1], xv0);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv0[0], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv0[0], hi0, 0, 0, 0);
+    PCCUP_T(1);   // first MFMA pair issued: acc tile + G[0] waits
     const int cnt_next = compact((j + 1) & 1);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[1], xv0[1], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[1], xv0[1], hi0, 0, 0, 0);
+    PCCUP_T(2);   // compaction
     request_nb(j + 2);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[2], xv0[2], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[2], xv0[2], hi0, 0, 0, 0);
     load_wj(Wn, j + 1);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[3], xv0[3], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[3], xv0[3], hi0, 0, 0, 0);
+    PCCUP_T(3);   // requests
     PCC16_SYNC();
     read_records((j + 1) & 1, rn);
 #pragma unroll
@@ -267,10 +311,17 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv0[s], lo0, 0, 0, 0);
       hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
     }
+    PCCUP_T(4);   // rest of item 0's chains
     if (cnt_cur <= 16) acc_write(rc_[0], lo0, hi0);
     gather(0);
+    PCCUP_T(5);   // write-back + gather issue (records wait)
+#ifdef PCCUP_ABL_NO123   // timing ablation: items 1 .. 3 are not contracted
+#define PCCUP_LIVE(g) (cnt_cur > 16 * (g) + 1000000)
+#else
+#define PCCUP_LIVE(g) (cnt_cur > 16 * (g))
+#endif
 #define PCCUP_ITEM(g, LO, HI, PLO, PHI)                                                                \
-    if (cnt_cur > 16 * (g)) {                                                                          \
+    if (PCCUP_LIVE(g)) {                                                                          \
       const bool more = (g) + 1 < NI && cnt_cur > 16 * ((g) + 1);                                      \
       float xv[8];                                                                                     \
       shape(G[g][0], G[g][1], xv);                                                                     \
@@ -308,10 +359,19 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
         acc_write(r.y, lo, hi);
       }
     }
+#if PCC_CONV_STAMP
+    PCCUP_T(6);   // items 1 .. 3, overflow
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    st_sum[3] += tq[0] - st_last;   // loop back
+    for (int i = 1; i < 7; ++i) st_sum[3 + i] += tq[i] - tq[i - 1];
+    st_last = tq[6];
+#endif
     cnt_cur = cnt_next;
   };
 
   // prologue of the remainder: offset 0 compacted and gathered, offset 1 requested
+  PCC16_SYNC();
+  request_nb(0);
   cnt_cur = compact(0);
   request_nb(1);
   load_wj(W0, 0);
@@ -375,4 +435,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       }
     }
   }
+#if PCC_CONV_STAMP
+  if (lane == 0 && blockIdx.x >= 8192 && blockIdx.x < 8192 + 4096) {
+    for (int j = 0; j < PCC_NSTAMP; ++j) pcc_stamp_buf[(blockIdx.x - 8192) * PCC_NSTAMP + j] = st_sum[j];
+  }
+#endif
 }

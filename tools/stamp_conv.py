@@ -17,7 +17,11 @@ sys.path.insert(0, ROOT)
 PKG = "demo-learned-point-cloud-compression_amd"
 NAMES = ["top", "compact(k+1)", "load_nb(k+2)", "w/slots/gather issue", "acc read", "gather wait+shape",
          "mfma+write", "pre-barrier", "barrier", "tail"]
-if os.environ.get("PCC_CONV16"):
+if os.environ.get("PCC_CONVUP"):
+    NAMES = ["X loads issued", "-", "wait X + sibling product", "loop back (+ tiles to LDS, prologue)", "tile + G[0] wait, MFMA pair 0",
+             "compaction, MFMA pair 1", "requests, MFMA pairs 2-3", "sync + records issue, MFMA pairs 4-7", "write-back, records wait, gather 0",
+             "items 1-3 + overflow"]
+elif os.environ.get("PCC_CONV16"):
     NAMES = ["loop back", "acc0 read + compact(k+1)", "requests + records", "item 0", "items 1-3 + gathers", "-", "-", "-",
              "-", "-"]
 
