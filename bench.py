@@ -48,35 +48,48 @@ def conv_algorithmic(n_out, n_in, cin, cout, k_vol, pairs):
     return nbytes, 2 * pairs * cin * cout
 
 
-def cpu_baseline(wl, frame, n_sample, threads, budget_s=20.0):
-    """CPU restatement (oracle) on a bounded spatial crop of the same frame.  A small crop is timed
-    first; the reported sample is then sized so that it takes about `budget_s` seconds (the whole
-    frame if that fits)."""
+def cpu_baseline(wl, frame, n_sample, threads, runs=5, warmups=2):
+    """SURVEY.md §8(d) protocol for the CPU leg: the oracle (oracle/codec_ref.py, the C restatement under numpy
+    orchestration, OpenMP over rows) on the same frame — the WHOLE frame unless --cpu-sample asks for a spatial crop —
+    `warmups` untimed runs, then the median of `runs` timed runs of encode (Q = 3) + decode (last quality), with the
+    reference's stage split (E1-E7: codec_pipeline.py:218-225, D1-D6: codec_parallel.py:157-163) as medians per
+    stage.  Raises on any failure: a bench line without this leg is an unmeasured line."""
     from oracle.codec_ref import Oracle
     pts = frame["points"].astype(np.int64)
-    # spatial crop: the points nearest (Chebyshev distance) to the median keep the surface statistics
-    c = np.median(pts, axis=0)
-    order = np.argsort(np.abs(pts - c).max(axis=1), kind="stable")
+    whole = n_sample <= 0 or n_sample >= pts.shape[0]
+    if whole:
+        sample = frame
+    else:   # the points nearest (Chebyshev distance) to the median keep the surface statistics
+        c = np.median(pts, axis=0)
+        keep = np.argsort(np.abs(pts - c).max(axis=1), kind="stable")[:n_sample]
+        sample = {"points": frame["points"][keep], "colors": frame["colors"][keep]}
+    n = sample["points"].shape[0]
     o = Oracle(threads=threads)
-
-    def run(n):
-        whole = n >= pts.shape[0]
-        keep = order[:n]
-        sample = frame if whole else {"points": frame["points"][keep], "colors": frame["colors"][keep]}
-        t0 = time.time()
-        out, dbg = o.compress([dict(sample)], SETTINGS)
-        t1 = time.time()
+    enc_s, dec_s, enc_st, dec_st, full = [], [], [], [], None
+    for it in range(warmups + runs):
+        t0 = time.perf_counter()
+        out, _dbg = o.compress([dict(sample)], SETTINGS)
+        t1 = time.perf_counter()
         rec = o.decompress(out[len(SETTINGS)])
-        return sample["points"].shape[0], t0, t1, time.time(), (out, rec) if whole else None
-
-    n, t0, t1, t2, full = run(min(n_sample, pts.shape[0]))
-    scale = budget_s / max(t2 - t0, 1e-3)
-    if scale > 1.5 and n < pts.shape[0]:
-        n, t0, t1, t2, full = run(int(min(pts.shape[0], n * scale)))
-    return {"value": (n / 1.0e6) / (t2 - t0), "unit": "frames/s (1M-point equivalent, linear in points)",
-            "cores": threads, "kind": "port",
-            "sample": f"{n}-point spatial crop of the same frame, Q=3 encode {t1 - t0:.2f}s + decode {t2 - t1:.2f}s, "
-                      f"oracle/ C restatement with OpenMP"}, full
+        t2 = time.perf_counter()
+        if it >= warmups:
+            enc_s.append(t1 - t0)
+            dec_s.append(t2 - t1)
+            enc_st.append(dict(o.enc_times))
+            dec_st.append(dict(o.dec_times))
+        if whole:
+            full = (out, rec)
+    med = lambda v: float(np.median(np.asarray(v)))    # noqa: E731
+    enc, dec = med(enc_s), med(dec_s)
+    total = med([a + b for a, b in zip(enc_s, dec_s)])
+    stages = {"encode": {k: med([d[k] for d in enc_st]) for k in enc_st[0]},
+              "decode": {k: med([d[k] for d in dec_st]) for k in dec_st[0]}}
+    return {"value": (n / 1.0e6) / total, "unit": "frames/s (1M-point equivalent, linear in points)",
+            "cores": threads, "kind": "port", "runs": runs, "warmups": warmups,
+            "encode_s": enc, "decode_s": dec, "total_s": total, "stages": stages,
+            "sample": (f"{'the whole' if whole else 'a spatial crop of the'} bench frame ({n} points), Q=3 encode + "
+                       f"decode of the last quality; median of {runs} runs after {warmups} warm-ups; oracle/ C "
+                       f"restatement with OpenMP on {threads} threads")}, full
 
 
 def main():
@@ -85,7 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=60_000)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="points of the CPU baseline's sample (0 = the whole frame)")
+    ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="also report throughput with this many GOPs in flight (0/1 = skip)")
@@ -193,6 +207,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_rank = {}   # N > 1: ms per step of every rank, per timed region
+
     def timed(host, enc=enc):
         fence()
         t_start = time.perf_counter()
@@ -205,6 +221,9 @@ def main():
         dt = time.perf_counter() - t_start
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, t)
+            per_rank[("host" if host else "hbm", id(enc))] = [1e3 * float(v.item()) / args.steps for v in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         # per-step spread on stderr: one GOP that takes twice as long (a one-time set-up inside the runtime, a throttled
@@ -380,11 +399,10 @@ def main():
 
     cpu, oracle_full = None, None
     if rank == 0 and not tiled_mode and not args.no_cpu_baseline:
-        try:
-            abi = importlib.import_module(PKG + "._abi")
-            cpu, oracle_full = cpu_baseline(wl, frames[0], args.cpu_sample, abi.host_cpu_budget())
-        except Exception as e:      # the oracle is only a reported baseline; never fail the bench on it
-            log("cpu_baseline failed:", repr(e))
+        abi = importlib.import_module(PKG + "._abi")
+        t0 = time.time()
+        cpu, oracle_full = cpu_baseline(wl, frames[0], args.cpu_sample, abi.host_cpu_budget(), runs=args.cpu_runs)
+        log(f"cpu_baseline in {time.time() - t0:.1f}s: encode {cpu['encode_s']:.2f}s decode {cpu['decode_s']:.2f}s", cpu["stages"])
 
     # ---- distortion (BASELINE.json's metric names D1-PSNR; the reference logs none — SURVEY.md §8d): MPEG pc_error
     # point-to-point D1 and luma PSNR of the decoded frame against the source, outside the timed region; for the HIP
@@ -460,6 +478,9 @@ def main():
                       "peak": quality["hip"]["peak"],
                       "reconstruction_equals_oracle": quality.get("reconstruction_equals_oracle"),
                       "containers_equal_oracle": quality.get("containers_equal_oracle")} if quality else None),
+            "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "backend": (backend + (" (RCCL over xGMI)" if backend == "nccl" else "")) if dist is not None else None,
+            "ms_per_step_per_rank": per_rank.get(("host", id(enc))),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "throughput_in_flight": inflight,

@@ -22,7 +22,7 @@ from .sparse import SparseTensor
 
 
 class DecompressionPipeline:
-    def __init__(self, device=0, slots=3, output="numpy", stage_sync=None, engine=None):
+    def __init__(self, device=0, slots=3, output="numpy", stage_sync=None, engine=None, base_path=None):
         self.device = torch.device("cuda", device)
         # "native": one pcc_decode_gop call per container (csrc/codec.hip); "ops": the reference's stage
         # methods one by one over the op-level C-ABI (same reconstruction, bit for bit)
@@ -33,7 +33,8 @@ class DecompressionPipeline:
         # holds per-stage wall times; False (default, PCC_STAGE_SYNC=1 overrides): stages are enqueued
         # back to back like the reference's asynchronous torch ops and only data hand-overs wait
         self.stage_sync = (os.environ.get("PCC_STAGE_SYNC", "0") == "1") if stage_sync is None else bool(stage_sync)
-        base_path = "./unified/results/"
+        # as the reference (codec_parallel.py:48-49); PCC_MODEL_BASE or the argument name another directory
+        base_path = base_path or os.environ.get("PCC_MODEL_BASE", "./unified/results/")
         self.decompression_model = self.load_model(base_path)
         self.output = output                  # "numpy" (reference behaviour) or "device"
         self._slots = queue.Queue()

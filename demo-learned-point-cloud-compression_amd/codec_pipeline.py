@@ -54,7 +54,8 @@ def _to_dev_as_is(a, keep, other, device):
 
 
 class CompressionPipeline:
-    def __init__(self, settings, device=0, slots=3, stage_sync=None, engine=None, container_version=None):
+    def __init__(self, settings, device=0, slots=3, stage_sync=None, engine=None, container_version=None,
+                 base_path=None):
         self.device = torch.device("cuda", device)
         # 0 (default): the reference's container, y / z strings coded by the host coder in CompressAI's format;
         # 1 (or PCC_CONTAINER_VERSION=1): flagged extension, y / z strings in the GPU coder's interleaved form
@@ -71,7 +72,9 @@ class CompressionPipeline:
         # back to back like the reference's asynchronous torch ops and only data hand-overs wait
         self.stage_sync = (os.environ.get("PCC_STAGE_SYNC", "0") == "1") if stage_sync is None else bool(stage_sync)
         self.settings = [[float(q[0]), float(q[1])] for q in settings]
-        base_path = "./unified/results/"          # as the reference; without that directory the in-tree checkpoint is used
+        # as the reference (codec_pipeline.py:57-58); PCC_MODEL_BASE or the argument name another directory; without a
+        # <base_path>/demo_small there, the in-tree checkpoint is used
+        base_path = base_path or os.environ.get("PCC_MODEL_BASE", "./unified/results/")
         self.compression_model = self.load_model(base_path)
         self._slots = queue.Queue()
         if self.engine == "native":

@@ -1015,6 +1015,9 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   hipStream_t st = ctx->stream;
   PCC_HIP(hipSetDevice(cd->device));
   PCC_TRY(pcc_sync(ctx));  // the previous call's tensors are dead from here on
+  // ... and so are its colour uploads: a call that left early (duplicate coordinates, a coordinate out of range) may have
+  // returned with DMAs of cd->up_stream still writing into pool memory
+  if (cd->up_stream) PCC_HIP(hipStreamSynchronize(cd->up_stream));
   cd->pool.reset();
   cd->events_used = 0;
   cd->sets.clear();
@@ -1083,7 +1086,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       hipLaunchKernelGGL(k_frames_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *frames, n, keys, flag);
       PCC_CHECK_LAUNCH();
     } else {
-      PCC_TRY(pcc_morton_keys(ctx, d_coords, n, keys, flag));
+      PCC_TRY(pcc_morton_keys_batch(ctx, d_coords, n, n_frames, keys, flag));   // an index >= n_frames raises the flag
     }
     // Morton keys of int16 coordinates fill bytes 0-5, the frame index the bytes above: the passes are known without a
     // look at the keys (and without the host round trip behind it); a byte that happens to be constant costs one
@@ -1104,7 +1107,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_TRY(pcc_level_counts(ctx, keys, n, 0, 5, level_n.data(), &dup));
     PCC_HIP(hipStreamSynchronize(st));
     PCC_REQUIRE(*(int32_t*)cd->pin_flag.p == 0, PCC_E_RANGE,
-                "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0,65534]");
+                "pcc_encode_gop: coordinate outside [-32768,32767] or batch index outside [0, n_frames)");
     PCC_REQUIRE(!dup, PCC_E_DUP, "pcc_encode_gop: duplicate coordinates");
     if (frames) root_keys.assign((const uint64_t*)(cd->pin_flag.p + 64), (const uint64_t*)(cd->pin_flag.p + 64) + 2 * frames->nf);
     x = {new_set(cd, keys, n, 1, n_frames), f, 4};
@@ -1596,6 +1599,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   hipStream_t st = ctx->stream;
   PCC_HIP(hipSetDevice(cd->device));
   PCC_TRY(pcc_sync(ctx));
+  if (cd->up_stream) PCC_HIP(hipStreamSynchronize(cd->up_stream));   // an encode on this codec that left early (see there)
   cd->pool.reset();
   cd->events_used = 0;
   cd->sets.clear();

@@ -81,6 +81,8 @@ bool pcc_conv_up_fused();
 // conv.hip: frees the operand-ordered weight copies of a context (pcc_destroy)
 void pcc_wcache_free(pcc_ctx* ctx);
 // conv.hip: pcc_sparse_conv_head_up on input rows whose 32 channels are stored in the order kConv16Perm below
+// sort.hip: pcc_morton_keys that also flags batch indexes >= n_batch
+int pcc_morton_keys_batch(pcc_ctx* ctx, const int32_t* d_coords, int64_t n, int n_batch, uint64_t* d_keys, int32_t* d_flag);
 // sort.hip: pcc_sort_pairs on given key bytes only (no look at the keys, no host round trip)
 int pcc_sort_pairs_bytes(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64_t n, unsigned byte_mask);
 // sort.hip: canonical order + rows in that order of a small coordinate set given by its Morton keys

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
     if (t >= 0 && i < n) {
       sv = ssym[i];
       rv = sidx ? (int)sidx[i] : (int)(i / idx_run);
+      rv = rv < tv.n_cdf ? rv : tv.n_cdf - 1;   // a table index out of range never reaches the LDS tables (the entry points check what they can)
     }
   };
   // kEncAhead steps of symbols and table indexes are in flight: a step's own arithmetic is a few hundred cycles, a
@@ -426,7 +427,9 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   auto fetch_idx = [&](int64_t t) -> int {
     const int64_t i = base + t * kLanes + lane;
     if (t >= T || i >= n) return 0;
-    return idx ? (int)idx[i] : (int)(i / idx_run);
+    const int r = idx ? (int)idx[i] : (int)(i / idx_run);
+    if (r >= tv.n_cdf) bad |= 4;   // reported through the status word; the tables are read at the last row instead
+    return r < tv.n_cdf ? r : tv.n_cdf - 1;
   };
   int r_q[kDecAhead];
 #pragma unroll
@@ -496,8 +499,8 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
     if (act) sym[i] = value + off_sym;
    }
   }
-  const unsigned long long b1 = __ballot((bad & 1) != 0), b2 = __ballot((bad & 2) != 0);
-  if (lane == 0 && (b1 | b2) != 0ull) atomicOr(status, (b1 ? 1 : 0) | (b2 ? 2 : 0));
+  const unsigned long long b1 = __ballot((bad & 1) != 0), b2 = __ballot((bad & 2) != 0), b4 = __ballot((bad & 4) != 0);
+  if (lane == 0 && (b1 | b2 | b4) != 0ull) atomicOr(status, (b1 ? 1 : 0) | (b2 ? 2 : 0) | (b4 ? 4 : 0));
 }
 
 // ======================================================================== C-ABI
@@ -511,8 +514,8 @@ int pcc_rans_encode_dev_async(pcc_ctx* ctx, const pcc_rans_dev* tables, const in
                               long long* d_lens, int attempt) {
   PCC_REQUIRE(ctx && tables && d_out && d_lens && n >= 0 && n < ((int64_t)1 << 32) && n_streams >= 1 && n_streams <= 64 &&
                   cap_each >= 4 * (kHeaderWords + 1 + 2 * kLanes) && cap_each % 4 == 0 && (n == 0 || d_sym) &&
-                  (d_idx || idx_run >= 1),
-              PCC_E_ARG, "pcc_rans_encode_dev: bad argument");
+                  (d_idx || (idx_run >= 1 && (n + idx_run - 1) / idx_run <= tables->n_cdf)),
+              PCC_E_ARG, "pcc_rans_encode_dev: bad argument (without an index array, symbol i uses table i / idx_run)");
   PCC_REQUIRE((uintptr_t)d_out % 4 == 0, PCC_E_ARG, "pcc_rans_encode_dev: output must be 4-byte aligned");
   hipStream_t st = ctx->stream;
   const int64_t T = steps_for(n), nc = chunks_for(n, T);
@@ -536,28 +539,26 @@ extern "C" int pcc_rans_encode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, con
                                    int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
                                    int64_t* h_lens) {
   PCC_REQUIRE(ctx && h_lens && n_streams >= 1 && n_streams <= 64, PCC_E_ARG, "pcc_rans_encode_dev: bad argument");
-  long long* d_lens = nullptr;
-  PCC_HIP(hipMalloc((void**)&d_lens, 64 * 8));
+  // the packing kernel writes the stream lengths straight into the context's pinned host block (device-visible): no
+  // device allocation per call, no copy
+  long long* d_lens = (long long*)ctx->pinned + 64;   // bytes 512 .. 1023 of the 4-KB block
   int rc = PCC_OK;
   for (int attempt = 0; attempt < 2; ++attempt) {
     rc = pcc_rans_encode_dev_async(ctx, tables, d_sym, d_idx, idx_run, n, n_streams, d_out, cap_each, d_lens, attempt);
     if (rc != PCC_OK) break;
-    long long h[64];
-    if (hipMemcpyAsync(h, d_lens, (size_t)n_streams * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
       rc = PCC_E_HIP;
-      pcc_set_error("pcc_rans_encode_dev: read-back of the stream lengths failed");
+      pcc_set_error("pcc_rans_encode_dev: the coder launches failed");
       break;
     }
     rc = PCC_OK;
     for (int s = 0; s < n_streams; ++s) {
-      h_lens[s] = h[s];
-      if (h[s] < 0) rc = PCC_E_NOMEM;
+      h_lens[s] = ((volatile long long*)d_lens)[s];
+      if (h_lens[s] < 0) rc = PCC_E_NOMEM;
     }
     if (rc == PCC_OK) break;
     pcc_set_error("pcc_rans_encode_dev: a stream does not fit %lld bytes", (long long)cap_each);
   }
-  (void)hipFree(d_lens);
   return rc;
 }
 

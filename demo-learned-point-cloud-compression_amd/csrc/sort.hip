@@ -17,12 +17,13 @@
 #define RS_WAVES (RS_THREADS / 64)
 
 // ---------------------------------------------------------------- key kernels
+// n_batch: batch indexes must lie below it (65535 = any legal index)
 __global__ void k_morton_keys(const int4* __restrict__ coords, int64_t n,
-                              uint64_t* __restrict__ keys, int32_t* __restrict__ flag) {
+                              uint64_t* __restrict__ keys, int32_t* __restrict__ flag, int n_batch = 65535) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int4 c = coords[i];  // (b,x,y,z)
-  bool bad = (c.x < 0) | (c.x > 65534) | (c.y < -32768) | (c.y > 32767) |
+  bool bad = (c.x < 0) | (c.x > 65534) | (c.x >= n_batch) | (c.y < -32768) | (c.y > 32767) |
              (c.z < -32768) | (c.z > 32767) | (c.w < -32768) | (c.w > 32767);
   if (bad) atomicOr(flag, 1);
   keys[i] = pcc_morton(c.x, c.y, c.z, c.w);
@@ -473,7 +474,18 @@ extern "C" int pcc_morton_keys(pcc_ctx* ctx, const int32_t* d_coords, int64_t n,
   PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_keys && d_flag)), PCC_E_ARG, "pcc_morton_keys: null arg");
   if (n <= 0) return PCC_OK;
   hipLaunchKernelGGL(k_morton_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
-                     (const int4*)d_coords, n, d_keys, d_flag);
+                     (const int4*)d_coords, n, d_keys, d_flag, 65535);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+// internal (common.h): pcc_morton_keys that also flags batch indexes >= n_batch — the whole-GOP encoder picks the radix
+// passes of its input sort from the frame count alone, which is only right when every index lies below it
+int pcc_morton_keys_batch(pcc_ctx* ctx, const int32_t* d_coords, int64_t n, int n_batch, uint64_t* d_keys, int32_t* d_flag) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_coords && d_keys && d_flag)) && n_batch >= 1, PCC_E_ARG, "pcc_morton_keys: null arg");
+  if (n <= 0) return PCC_OK;
+  hipLaunchKernelGGL(k_morton_keys, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                     (const int4*)d_coords, n, d_keys, d_flag, n_batch);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import runtime as _rt
+from . import tables as _tables
 from .sparse import SparseTensor, CoordSet
 from .entropy import EntropyBottleneck, GaussianConditional
 
@@ -35,8 +36,10 @@ def load_checkpoint(name="demo_small"):
 def load_model_dir(base_path, model_name):
     """What the reference's load_model(base_path) reads (sender/encoder/codec_pipeline.py:56-72): the directory
     <base_path>/<model_name>/ with config.yaml and the weights.  Returns (config["model"], tensors).
-      * weights.npz there (this build's checkpoint format: the tensor names of tools/make_checkpoint.py, CDF tables
-        included) is loaded; config.yaml, when present, supplies the model section;
+      * weights.npz there (this build's checkpoint format: the tensor names of tools/make_checkpoint.py; the entropy
+        models either as integer CDF tables or as raw parameters — CompressAI's state_dict names, tables.py — from
+        which ColorModel.update() builds the tables) is loaded; config.yaml, when present, supplies the model section
+        (name, channels, latent_channels, hyper_channels), which ColorModel checks against the tensors;
       * only weights.pt there — a torch state_dict of the reference's model package, which is not in its tree, so its
         key names, MinkowskiEngine kernel layouts and CompressAI table builders cannot be restated here: refused with
         that message rather than silently replaced;
@@ -221,13 +224,55 @@ class EntropyModel:
         return a / (b + stdev)
 
 
+def model_widths(tensors):
+    """(C, C_y, C_z) of a checkpoint: hidden width, latent channels, hyper-latent channels — read off the layers that fix
+    them (the native graph of csrc/codec.hip takes the same tensors)"""
+    c = int(tensors["g_a.conv0.weight"].shape[2])
+    cy = int(tensors["g_a.conv3.weight"].shape[2])
+    cz = int(tensors["h_a.down1.weight"].shape[2])
+    return c, cy, cz
+
+
+# layer -> (kernel volume, input width, output width) in terms of the config's widths: the architecture of DESIGN.md §2
+def _layer_shapes(c, cy, cz):
+    sh = {"g_a.conv0": (27, 4, c), "g_a.conv3": (27, c, cy), "h_a.conv0": (27, cy, c), "h_a.down0": (8, c, c),
+          "h_a.down1": (8, c, cz), "h_s.up0": (8, cz, c), "h_s.up1": (8, c, c), "h_s.conv0": (27, c, 2 * cy)}
+    for j in range(3):
+        sh[f"g_a.down{j}"] = (8, c, c)
+        if j:
+            sh[f"g_a.conv{j}"] = (27, c, c)
+        sh[f"g_s.up{j}"] = (8, cy if j == 0 else c, c)
+        sh[f"g_s.conv{j}"] = (27, c, c)
+    return sh
+
+
 class ColorModel:
+    """`model.ColorModel(config["model"])` (codec_pipeline.py:65).  config: {"name", "channels" (hidden width C),
+    "latent_channels" (C_y), "hyper_channels" (C_z)} — the widths of the layer graph of DESIGN.md §2 (its depth is fixed
+    by the reference's own constants: strides 8 and 32, codec_pipeline.py:308, codec_parallel.py:296-311).  Widths the
+    config leaves out are read off the tensors; widths it names must be the tensors'."""
+
     def __init__(self, config=None, tensors=None):
-        self.config = config or {"name": "demo_small"}
+        self.config = dict(config or {"name": "demo_small"})
         self.tensors = tensors if tensors is not None else load_checkpoint(self.config.get("name", "demo_small"))
         self.device = None
         self.params = None
         self.g_a = self.g_s = self.entropy_model = None
+        self._check_config()
+
+    def _check_config(self):
+        c, cy, cz = model_widths(self.tensors)
+        want = (self.config.get("channels", c), self.config.get("latent_channels", cy), self.config.get("hyper_channels", cz))
+        if tuple(int(v) for v in want) != (c, cy, cz):
+            raise ValueError(f"model config asks for widths (C, C_y, C_z) = {tuple(want)}, the weights have {(c, cy, cz)}")
+        self.config.update({"channels": c, "latent_channels": cy, "hyper_channels": cz})
+        for name, shape in _layer_shapes(c, cy, cz).items():
+            got = tuple(self.tensors[name + ".weight"].shape)
+            if got != shape:
+                raise ValueError(f"layer {name}: weight {got}, the config's graph needs {shape}")
+            if tuple(self.tensors[name + ".bias"].shape) != (shape[2],):
+                raise ValueError(f"layer {name}: bias {tuple(self.tensors[name + '.bias'].shape)}, expected ({shape[2]},)")
+        self.tensors["config.channels"] = np.array([c, cy, cz], dtype=np.int32)
 
     def load_state_dict(self, state):
         if state:
@@ -239,13 +284,19 @@ class ColorModel:
         self.params = _Params(self.tensors, self.device)
         self.g_a = AnalysisTransform(self.params)
         self.g_s = SynthesisTransform(self.params)
+        _tables.update_tensors(self.tensors)      # a checkpoint with raw entropy parameters only: tables on first use
         self.entropy_model = EntropyModel(self.tensors, self.params)
         return self
 
-    def update(self):
-        # CompressAI's update() builds the integer CDF tables; here they ship
-        # pre-quantised in the checkpoint (tools/make_checkpoint.py).
-        return True
+    def update(self, force=False):
+        """CompressAI's update() (codec_pipeline.py:69): builds the integer CDF tables of entropy_bottleneck and
+        gaussian_conditional from the raw entropy parameters of the checkpoint (tables.py) — the ones it lacks, or all of
+        them with force=True.  Returns True when tables were built.  Call before the native codec is created from
+        `self.tensors` (load_model does)."""
+        updated = _tables.update_tensors(self.tensors, force=force)
+        if updated and self.device is not None:
+            self.entropy_model = EntropyModel(self.tensors, self.params)
+        return updated
 
     def eval(self):
         return self

@@ -428,8 +428,10 @@ int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx,
  *            pcc_rans_dev_bound(n) bytes always suffice; h_lens[s] = bytes
  * encode synchronises the stream once (the lengths); decode does not: it takes
  * the header fields pcc_rans_stream_info checked on the host copy of the stream
- * and ORs d_status (int32, device) with 1 / 2 if a chunk runs out of words / an
- * escape is malformed — test it after the next synchronisation. */
+ * and ORs d_status (int32, device) with 1 / 2 / 4 if a chunk runs out of words /
+ * an escape is malformed / a table index is not below n_cdf (the last row is
+ * used instead) — test it after the next synchronisation.  encode clamps table
+ * indexes the same way; with d_idx == NULL it refuses n > idx_run * n_cdf. */
 typedef struct pcc_rans_dev pcc_rans_dev;
 pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitch,
                                   const int32_t* h_sizes, const int32_t* h_offsets,
@@ -599,7 +601,10 @@ int pcc_decode_fetch_packed(pcc_codec* codec, int32_t* points, float* colors);
  * (host or device memory); pcc_container_points gives the number of points a
  * container announces (sum over frames of its finest k, an upper bound of what
  * is decoded; host-only parse, nothing beyond the slot bounds is validated).
- * More points decoded than cap_points: PCC_E_ARG, nothing is written. */
+ * More points decoded than cap_points: PCC_E_ARG, nothing is written.  Any
+ * other error (PCC_E_STREAM from a malformed version-1 stream is only known when
+ * the GPU coder's status word comes back, after the transfers were queued):
+ * the contents of points / colors are undefined. */
 int pcc_container_points(const uint8_t* h_in, int64_t len, int64_t* h_n_points,
                          int32_t* h_n_frames);
 int pcc_decode_gop_packed(pcc_codec* codec, const uint8_t* h_in, int64_t len,

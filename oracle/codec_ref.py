@@ -16,6 +16,7 @@ product loads (tools/make_checkpoint.py); the checkpoint is data, not code.
 import ctypes as C
 import os
 import struct
+import time
 import subprocess
 
 import numpy as np
@@ -337,10 +338,18 @@ class Oracle:
         return keys, self.linear(h, w, b), offs
 
     # ------------------------------------------------------------ pipeline
+    def _tick(self, times, key, t0):
+        """stage clock of the sequential restatement: the reference's stage keys (codec_pipeline.py:218-225 E1-E7,
+        codec_parallel.py:157-163 D1-D6); returns the new start"""
+        t1 = time.perf_counter()
+        times[key] = times.get(key, 0.0) + (t1 - t0)
+        return t1
+
     def compress(self, frames, settings, version=0):
         """frames: list of {"points": int[N,3], "colors": float[N,3]} -> ({1..Q: bytes}, debug dict).
         version 0: the reference's container (single rANS streams); 1: this build's flagged extension — the same
         fields, top byte of the first word 1, y / z strings in the interleaved form of the GPU coder"""
+        times, t0 = {}, time.perf_counter()
         pts, cols = [], []
         for f in frames:
             if "points" not in f:
@@ -356,12 +365,15 @@ class Oracle:
         ycoords = self.keys_to_coords(ykeys)
         yperm = self.canonical_perm(ycoords)
         y_sorted, ycoords_sorted = y[yperm], ycoords[yperm]
+        t0 = self._tick(times, "analysis", t0)
         # geometry: per frame, coords/8 (shared/utils.py:173)
         yoffs = self.batch_offsets(ykeys, n_batch)
         points_streams = [self.octree_encode(ycoords[yoffs[f]:yoffs[f + 1], 1:] // 8, 4096)
                           for f in range(n_batch)]
+        t0 = self._tick(times, "geometry_compression", t0)
         # hyper path
         zkeys, z = self.h_a(ykeys, y)
+        t0 = self._tick(times, "hyper_analysis", t0)
         zcoords = self.keys_to_coords(zkeys)
         zperm = self.canonical_perm(zcoords)
         zsym, zhat_sorted = self.factorized_quant(z[zperm])
@@ -372,19 +384,25 @@ class Oracle:
             z_string = self.rans_encode(zsym, np.repeat(np.arange(cz, dtype=np.int32), zsym.shape[1]),
                                         "entropy_bottleneck")
         zk2, zhat = self.sparse_tensor(zcoords[zperm], zhat_sorted)
+        t0 = self._tick(times, "factorized_model", t0)
         pkeys, params = self.h_s(zk2, zhat)
+        t0 = self._tick(times, "hyper_synthesis", t0)
         rows = self.lookup(pkeys, self.morton_keys(ycoords_sorted))
         prm = np.where(rows[:, None] >= 0, params[np.maximum(rows, 0)], np.float32(0)).astype(np.float32)
         scale = np.concatenate([self.scale_nn([q]) + self.eps for q in settings], 0).astype(np.float32)
         sym, idx = self.gaussian_quant(y_sorted, prm, scale)
-        out = {}
+        out, y_strings = {}, []
         for qi, q in enumerate(settings):
             if version == 1:
-                y_string = self.rans_interleaved_encode(sym[qi], idx[qi], "gaussian_conditional")
+                y_strings.append(self.rans_interleaved_encode(sym[qi], idx[qi], "gaussian_conditional"))
             else:
-                y_string = self.rans_encode(sym[qi], idx[qi], "gaussian_conditional")
-            out[qi + 1] = self.make_bitstream(y_string, z_string, y_sorted.shape[0], zsym.shape[1], points_streams,
+                y_strings.append(self.rans_encode(sym[qi], idx[qi], "gaussian_conditional"))
+        t0 = self._tick(times, "gaussian_model", t0)
+        for qi, q in enumerate(settings):
+            out[qi + 1] = self.make_bitstream(y_strings[qi], z_string, y_sorted.shape[0], zsym.shape[1], points_streams,
                                               k, q, version)
+        self._tick(times, "bitstream_writing", t0)
+        self.enc_times = times
         dbg = {"ykeys": ykeys, "y": y, "k": k, "zkeys": zkeys, "z": z, "params_keys": pkeys, "params": params,
                "sym": sym, "idx": idx, "zsym": zsym, "points_streams": points_streams, "z_string": z_string,
                "scale": scale, "num_points": coords.shape[0]}
@@ -421,11 +439,14 @@ class Oracle:
         return (struct.unpack_from(">I", data, 0)[0] >> 24) & 0xFF
 
     def decompress(self, data):
+        times, t0 = {}, time.perf_counter()
         version = self.container_version(data)
         assert version in (0, 1)
         y_string, z_string, n_y, n_z, streams, ks, q = self.read_bitstream(data)
         n_batch = len(streams)
+        t0 = self._tick(times, "bitstream_reading", t0)
         pts = [self.octree_decode(s) * 8 for s in streams]
+        t0 = self._tick(times, "geometry_decompression", t0)
         ycoords = np.concatenate([np.concatenate([np.full((p.shape[0], 1), i, np.int32), p], 1)
                                   for i, p in enumerate(pts)], 0).astype(np.int32)
         ykeys = np.sort(self.morton_keys(ycoords))
@@ -441,7 +462,9 @@ class Oracle:
             zsym = self.rans_decode(z_string, np.repeat(np.arange(cz, dtype=np.int32), n_z), "entropy_bottleneck")
         zhat_sorted = self.factorized_dequant(zsym.reshape(cz, n_z))
         zk2, zhat = self.sparse_tensor(zcoords_sorted, zhat_sorted)
+        t0 = self._tick(times, "factorized_model", t0)
         pkeys, params = self.h_s(zk2, zhat)
+        t0 = self._tick(times, "hyper_synthesis", t0)
         ycoords_sorted = ycoords[self.canonical_perm(ycoords)]
         assert ycoords_sorted.shape[0] == n_y
         rows = self.lookup(pkeys, self.morton_keys(ycoords_sorted))
@@ -454,6 +477,7 @@ class Oracle:
             sym = self.rans_decode(y_string, idx, "gaussian_conditional")
         yhat_sorted = self.gaussian_dequant(sym.reshape(idx.shape), prm, scale[0])
         yk2, yhat = self.sparse_tensor(ycoords_sorted, yhat_sorted)
+        t0 = self._tick(times, "guassian_model", t0)
         xkeys, rgb, offs = self.g_s(yk2, yhat, ks, n_batch)
         coords = self.keys_to_coords(xkeys)
         frames = []
@@ -461,4 +485,6 @@ class Oracle:
             c = np.nan_to_num(rgb[offs[f]:offs[f + 1]], nan=0.0)
             c = np.clip(c * 255.0, 0, 255) / 255
             frames.append({"points": coords[offs[f]:offs[f + 1], 1:], "colors": c})
+        self._tick(times, "synthesis_transform", t0)
+        self.dec_times = times
         return frames

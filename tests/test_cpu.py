@@ -411,6 +411,8 @@ def test_load_model_directory(tmp_path):
     cfg, t = model.load_model_dir(str(tmp_path), "demo_small")
     assert cfg == {"name": "demo_small", "channels": 32}
     assert np.array_equal(t["g_a.conv0.bias"], changed["g_a.conv0.bias"]) and set(t) == set(ref)
+    m = model.ColorModel(cfg, t)
+    assert m.config["latent_channels"] == 32 and m.config["hyper_channels"] == 32
 
 
 def test_rans_bypass_escape_known_answers(oracle):
@@ -445,8 +447,8 @@ def test_rans_bypass_escape_known_answers(oracle):
 
 
 def test_pmf_to_quantized_cdf_known_answers():
-    """CompressAI's pmf_to_quantized_cdf (cpp_exts/ops/ops.cpp; restated in tools/make_checkpoint.py, which built the
-    tables of the checkpoint), by hand at precision 4 (total 16):
+    """CompressAI's pmf_to_quantized_cdf (cpp_exts/ops/ops.cpp; restated in the product's tables.py, which model.update()
+    runs, and statement by statement in oracle/tables_ref.py), by hand at precision 4 (total 16):
 
     pmf [0.6, 0, 0.3, 0, 0.1]: round(p * 16) = [10, 0, 5, 0, 2], sum 17; (16 * f) // 17 = [9, 0, 4, 0, 1];
       partial sums [0, 9, 9, 13, 13, 14], last forced to 16 -> [0, 9, 9, 13, 13, 16].
@@ -458,14 +460,99 @@ def test_pmf_to_quantized_cdf_known_answers():
       i = 2: frequencies [3, 9, 0, 4]; smallest > 1 is 3 at symbol 0 (< i): cdf[1..2] -= 1 -> [0, 2, 11, 12, 16]
     pmf [2.5/16, 13.5/16]: std::round rounds halves away from zero: [3, 14], sum 17; [48 // 17, 224 // 17] = [2, 13]
       -> [0, 2, 15] -> last forced: [0, 2, 16]"""
+    from oracle import tables_ref
+    for mk in (pkg("tables"), tables_ref):
+        assert mk.pmf_to_quantized_cdf([0.6, 0.0, 0.3, 0.0, 0.1], 4).tolist() == [0, 9, 10, 14, 15, 16]
+        assert mk.pmf_to_quantized_cdf([0.2, 0.55, 0.0, 0.25], 4).tolist() == [0, 2, 11, 12, 16]
+        assert mk.pmf_to_quantized_cdf([2.5 / 16, 13.5 / 16], 4).tolist() == [0, 2, 16]
+
+
+def test_update_rebuilds_the_checkpoint_tables_bit_for_bit():
+    """model.update() (codec_pipeline.py:69): ColorModel.update(force=True) rebuilds the integer CDF tables of the in-tree
+    checkpoint from its raw entropy parameters (EntropyBottleneck matrices / biases / quantiles, GaussianConditional
+    scale table) and gets the stored tables back bit for bit; a checkpoint stripped of its tables gets them from
+    update() (and from to(), which the pipelines call first); the oracle's element-by-element restatement of the
+    same builders agrees on every table"""
+    model, tables = pkg("model"), pkg("tables")
+    from oracle import tables_ref
+    ref = model.load_checkpoint("demo_small")
+    names = tables.EB_TABLES + tables.GC_TABLES
+    m = model.ColorModel({"name": "demo_small"}, {k: v.copy() for k, v in ref.items()})
+    assert m.update() is False                      # nothing missing: nothing built
+    assert m.update(force=True) is True
+    for k in names:
+        assert m.tensors[k].dtype == ref[k].dtype and np.array_equal(m.tensors[k], ref[k]), k
+    stripped = {k: v for k, v in ref.items() if k not in names}
+    m2 = model.ColorModel({"name": "demo_small"}, dict(stripped))
+    assert m2.update() is True and all(np.array_equal(m2.tensors[k], ref[k]) for k in names)
+    # oracle restatement
+    g = tables_ref.gaussian_tables(ref["gaussian_conditional.scale_table"])
+    for got, k in zip(g, tables.GC_TABLES):
+        assert np.array_equal(got, ref[k]), k
+    raw = tables.bottleneck_raw(ref)
+    b = tables_ref.bottleneck_tables(*raw)
+    for got, k in zip(b, tables.EB_TABLES):
+        assert np.array_equal(got, ref[k]), k
+    # neither tables nor raw parameters: refused
+    with pytest.raises(KeyError):
+        model.ColorModel({"name": "x"}, {k: v for k, v in stripped.items() if "._matrix" not in k}).update()
+
+
+def test_bottleneck_tables_of_a_learned_shape_density():
+    """EntropyBottleneck.update() on CompressAI's default density network (filters (3, 3, 3, 3): five matrices with
+    softplus, four tanh gates) with seeded parameters: product (vectorised) == oracle restatement (element by element),
+    every row a strictly increasing 16-bit CDF ending at 65536 whose support is [median - minima, median + maxima]"""
+    tables = pkg("tables")
+    from oracle import tables_ref
+    rng = np.random.default_rng(5)
+    ch, filters = 6, (1, 3, 3, 3, 3, 1)
+    mats = [rng.normal(0.3, 0.6, (ch, filters[i + 1], filters[i])).astype(np.float32) for i in range(5)]
+    biases = [rng.uniform(-0.5, 0.5, (ch, filters[i + 1], 1)).astype(np.float32) for i in range(5)]
+    factors = [rng.normal(0, 0.5, (ch, filters[i + 1], 1)).astype(np.float32) for i in range(4)]
+    med = rng.uniform(-2, 2, ch).astype(np.float32)
+    quant = np.stack([med - rng.uniform(3, 20, ch), med, med + rng.uniform(3, 20, ch)], 1).astype(np.float32).reshape(ch, 1, 3)
+    t = {f"entropy_bottleneck._matrix{i}": m for i, m in enumerate(mats)}
+    t.update({f"entropy_bottleneck._bias{i}": b for i, b in enumerate(biases)})
+    t.update({f"entropy_bottleneck._factor{i}": f for i, f in enumerate(factors)})
+    t["entropy_bottleneck.quantiles"] = quant
+    raw = tables.bottleneck_raw(t)
+    got = tables.bottleneck_tables(*raw)
+    want = tables_ref.bottleneck_tables(mats, biases, factors, quant)
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    medians, cdf, length, offset = got
+    for c in range(ch):
+        row = cdf[c, :length[c]]
+        assert row[0] == 0 and row[-1] == 65536 and np.all(np.diff(row) > 0)
+        assert length[c] == int(np.ceil(med[c] - quant[c, 0, 0])) + int(np.ceil(quant[c, 0, 2] - med[c])) + 3
+        assert offset[c] == -int(np.ceil(med[c] - quant[c, 0, 0]))
+
+
+def test_model_config_drives_the_layer_graph(tmp_path):
+    """config.yaml's model section (codec_pipeline.py:60-65): widths named there must be the tensors'; a model directory
+    written with other widths (raw entropy parameters only) loads, update() builds its tables, and the checkpoint blob of
+    the native codec carries the widths"""
+    model = pkg("model")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         mk = importlib.import_module("make_checkpoint")
     finally:
         sys.path.pop(0)
-    assert mk.pmf_to_quantized_cdf([0.6, 0.0, 0.3, 0.0, 0.1], 4).tolist() == [0, 9, 10, 14, 15, 16]
-    assert mk.pmf_to_quantized_cdf([0.2, 0.55, 0.0, 0.25], 4).tolist() == [0, 2, 11, 12, 16]
-    assert mk.pmf_to_quantized_cdf([2.5 / 16, 13.5 / 16], 4).tolist() == [0, 2, 16]
+    d = tmp_path / "demo_small"
+    mk.write_model_dir(str(d), 16, 24, 8)
+    cfg, t = model.load_model_dir(str(tmp_path), "demo_small")
+    assert cfg == {"name": "demo_small", "channels": 16, "latent_channels": 24, "hyper_channels": 8}
+    assert "entropy_bottleneck.quantized_cdf" not in t and "entropy_bottleneck._matrix0" in t
+    m = model.ColorModel(cfg, t)
+    assert m.update() is True
+    assert m.tensors["entropy_bottleneck.quantized_cdf"].shape[0] == 8 and model.model_widths(m.tensors) == (16, 24, 8)
+    assert m.tensors["config.channels"].tolist() == [16, 24, 8]
+    with pytest.raises(ValueError):
+        model.ColorModel({"name": "demo_small", "channels": 32}, dict(t))            # config and weights disagree
+    bad = dict(t)
+    bad["g_s.conv1.weight"] = np.zeros((27, 16, 8), np.float32)
+    with pytest.raises(ValueError):
+        model.ColorModel({"name": "demo_small"}, bad)                                # a layer off the config's graph
 
 
 def test_build_indexes_and_offset_dequantisation_known_answers(oracle):

@@ -239,3 +239,49 @@ def test_mfma_and_scalar_paths_agree_end_to_end(wl):
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(r.stdout.strip().splitlines()[-1])
     assert res[0] == res[1] == res[2]
+
+
+@pytest.mark.parametrize("widths", [(16, 24, 8), (32, 16, 32)])
+@pytest.mark.parametrize("engine", ["native", "ops"])
+def test_second_checkpoint_with_its_own_config(wl, tmp_path, widths, engine):
+    """load_model (codec_pipeline.py:56-72) on a model directory of its own: config.yaml names other widths (C, C_y, C_z),
+    weights.npz carries the seeded layers of those widths and RAW entropy parameters only; model.update() builds the
+    integer tables at load time (tables.py), the native graph runs the configured widths, and containers (both
+    versions) and reconstructions equal the oracle's — whose tables come from its own restatement of update()
+    (oracle/tables_ref.py)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import importlib
+    import sys
+    from oracle.codec_ref import Oracle
+    from oracle import tables_ref
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        mk = importlib.import_module("make_checkpoint")
+    finally:
+        sys.path.pop(0)
+    tables = pkg("tables")
+    base = tmp_path / "results"
+    mk.write_model_dir(str(base / "demo_small"), *widths)
+    t = mk.build(*widths, with_tables=False)
+    for a, k in zip(tables_ref.gaussian_tables(t["gaussian_conditional.scale_table"]), tables.GC_TABLES):
+        t[k] = a
+    for a, k in zip(tables_ref.bottleneck_tables(*tables.bottleneck_raw(t)), tables.EB_TABLES):
+        t[k] = a
+    np.savez(tmp_path / "oracle_ckpt.npz", **t)
+    oracle = Oracle(ckpt=str(tmp_path / "oracle_ckpt.npz"), threads=8)
+    frames = [wl.sphere_shell(40, 15.3, seed=3, offset=(-30, 12, -70)), wl.sphere_shell(24, 9.1, seed=4)]
+    settings = [[1.0, 0.0], [1, 1]]
+    for version in (0, 1):
+        e = pkg("codec_pipeline").CompressionPipeline(settings, slots=1, engine=engine, container_version=version,
+                                                      base_path=str(base))
+        d = pkg("codec_parallel").DecompressionPipeline(slots=1, engine=engine, base_path=str(base))
+        assert e.compression_model.config["channels"] == widths[0]
+        assert e.compression_model.config["latent_channels"] == widths[1]
+        out, _ = e.compress(wl.gop(copy_frames(frames)))
+        ref, _ = oracle.compress(frames, settings, version=version)
+        assert out[1] == ref[1] and out[2] == ref[2], f"containers differ from the oracle (version {version})"
+        rec, _ = d.decompress(out[2])
+        oref = oracle.decompress(ref[2])
+        for a, b in zip(rec, oref):
+            assert np.array_equal(a["points"], b["points"]) and np.array_equal(a["colors"], b["colors"])
