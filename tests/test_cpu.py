@@ -109,6 +109,22 @@ def test_oracle_reproduces_golden(oracle, name):
     assert all(0.5 < 8 * len(out[q]) / n < 12 for q in (1, 2, 3))
 
 
+@pytest.mark.parametrize("gop,version", [(0, 0), (5, 1), (8, 0)])
+def test_oracle_reproduces_sequence_golden(oracle, gop, version):
+    """tests/golden/zed_seq25.npz: 25 recorded ZED frames of the reference's evaluation/data/test_sequence as its encoder
+    service samples them (5 per 1-s segment), with digests of the oracle's containers / reconstructions per GOP: three of
+    the twelve GOPs re-run here (the GPU suite runs all twelve against the same digests)"""
+    import hashlib
+    with np.load(os.path.join(ROOT, "tests", "golden", "zed_seq25.npz")) as f:
+        g = {k: f[k] for k in f.files}
+    lo, hi = (int(v) for v in g["gops"][gop])
+    frames = [{"points": g[f"points_{i}"], "colors": g[f"colors_u8_{i}"].astype(np.float64) / 255.0} for i in range(lo, hi)]
+    out, _ = oracle.compress(frames, SETTINGS, version=version)
+    for q in (1, 2, 3):
+        assert hashlib.sha256(out[q]).hexdigest() == g[f"g{gop}_v{version}_container_{q}"].tobytes().decode()
+    assert _digest(oracle.decompress(out[3])) == g[f"g{gop}_decoded_3"].tobytes().decode()
+
+
 def test_oracle_roundtrip_properties(oracle, wl):
     frames = [wl.sphere_shell(32, 11.2, seed=1, offset=(-70, 3, 40)), wl.sphere_shell(24, 9.1, seed=2)]
     out, dbg = oracle.compress(frames, SETTINGS)

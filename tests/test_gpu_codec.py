@@ -111,6 +111,34 @@ def test_gops_of_changing_size_on_one_pipeline_pair(oracle, wl, version):
             assert digest(rec) == digest(rec_ref)
 
 
+@pytest.mark.parametrize("version", [0, 1])
+def test_recorded_sequence_at_the_reference_operating_point(wl, version):
+    """Real data at the operating point of the reference's services (sender/encoder/encoder.py:95-145,
+    shared/config.yaml:9-15): the 25 ZED frames its encoder samples from the first five seconds of
+    evaluation/data/test_sequence (int16 points with negative coordinates, 14k - 20k voxels each), as 5 GOPs of 5 and then
+    as GOPs of 1, 3, 5, 2, 4, 5, 5 frames, all on ONE encoder / decoder pair (pools and pinned buffers grown by one GOP
+    reused by the next), Q = 3: every container and every reconstruction equals the oracle's (digests of
+    tests/golden/zed_seq25.npz, generated by tools/make_golden.py and re-checked against the oracle by the CPU suite)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with np.load(os.path.join(GOLDEN, "zed_seq25.npz")) as f:
+        g = {k: f[k] for k in f.files}
+    frames = [{"points": g[f"points_{i}"], "colors": g[f"colors_u8_{i}"].astype(np.float64) / 255.0}
+              for i in range(int(g["n_frames"]))]
+    assert len(frames) >= 20 and min(int(f["points"].min()) for f in frames) < 0
+    e = pkg("codec_pipeline").CompressionPipeline(SETTINGS, slots=1, container_version=version)
+    d = pkg("codec_parallel").DecompressionPipeline(slots=1)
+    for gi, (lo, hi) in enumerate(g["gops"].tolist()):
+        out, side = e.compress(wl.gop(copy_frames(frames[lo:hi])))
+        assert side["gop_info"]["num_points"] == sum(f["points"].shape[0] for f in frames[lo:hi])
+        for q in (1, 2, 3):
+            assert hashlib.sha256(out[q]).hexdigest() == g[f"g{gi}_v{version}_container_{q}"].tobytes().decode(), \
+                f"GOP {gi} (frames {lo}..{hi}) container {q} differs from the oracle's"
+            rec, _ = d.decompress(out[q])
+            assert len(rec) == hi - lo
+            assert digest(rec) == g[f"g{gi}_decoded_{q}"].tobytes().decode(), f"GOP {gi} reconstruction {q} differs"
+
+
 def test_sideinfo_contract(enc, dec, wl):
     """key names read downstream (receiver/client/client.py:160-177, evaluation/plot.py:102-121)"""
     gop = wl.gop([wl.sphere_shell(24, 9.1, seed=6)])
