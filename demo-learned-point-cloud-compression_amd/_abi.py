@@ -60,6 +60,7 @@ PROTOTYPES = {
     "pcc_rans_stream_info": (i32, [vp, i64, pi64, pi64, pi64]),
     "pcc_rans_decode_dev": (i32, [vp, vp, vp, i64, i64, i64, i64, vp, i64, vp, vp]),
     "pcc_conv_prepare": (i32, [vp, vp, i32, i32, i32]),
+    "pcc_conv_kernel_name": (C.c_char_p, [i32, i32, i32, i32]),
     "pcc_conv_forget": (i32, [vp, vp]),
     "pcc_level_counts": (i32, [vp, vp, i64, i32, i32, pi64, C.POINTER(C.c_int)]),
     "pcc_down_coords_known": (i32, [vp, vp, i64, i32, vp, vp, i64, vp, i64]),

@@ -780,9 +780,11 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
     if (k.size() <= 7 || k.compare(k.size() - 7, 7, ".weight") != 0 || t.dtype != 0 || t.dims.size() != 3) continue;
     const std::string layer = k.substr(0, k.size() - 7);
     const bool is_up = layer.find(".up") != std::string::npos;
-    if (!is_up && (t.dims[0] == 27 || t.dims[0] == 8) && t.dims[1] == 32 && (t.dims[2] == 32 || t.dims[2] == 64) &&
-        cd->dev.count(k)) {
-      if (pcc_conv_prepare(ctx, cd->dev[k], (int)t.dims[0], 32, (int)t.dims[2]) != PCC_OK) {
+    // every conv layer whose widths have a matrix-core form (the model default's 32 -> 32 / 64, and any other multiples of
+    // 16 a config.yaml may name: pcc_conv_kernel_name)
+    if (!is_up && (t.dims[0] == 27 || t.dims[0] == 8) && t.dims[1] % 16 == 0 && t.dims[2] % 16 == 0 && t.dims[1] <= 128 &&
+        t.dims[2] <= 256 && cd->dev.count(k)) {
+      if (pcc_conv_prepare(ctx, cd->dev[k], (int)t.dims[0], (int)t.dims[1], (int)t.dims[2]) != PCC_OK) {
         for (auto& d : cd->dev) (void)hipFree(d.second);
         pcc_destroy(cd->ctx);
         delete cd;

@@ -34,6 +34,7 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 
 #include "conv16.h"
 #include "convup.h"
+#include "convgen.h"
 
 // The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound (252 MB: 108 MB of rule book, 128 MB of output).
 // One wave per 32-row tile, the product computed transposed (D[co][row] = W^T X^T) so that a lane ends up with 16
@@ -44,14 +45,22 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 // workgroup).  Offsets nobody in the tile has are skipped (11.7 of 27 are present on the bench frame).
 // 105 us (round 1: LDS tile, dword stores, weights from global, one gather ahead) -> 77 us.  Tried and slower: 64-row
 // windows (registers), index loads split between the half-waves (14 full-wave loads + v_permlane32_swap: +15 us).
+// NT: 32-column tiles of the output (cout = any multiple of 16 up to 32 NT: the model default's 32 is NT = 1; columns beyond
+// cout are computed on zero weights and not stored)
+// FULL: cout == 32 NT, known at compile time (no column predicate anywhere: the shipped shape)
+template <int NT, bool FULL>
 __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
     const float* __restrict__ in, const int32_t* __restrict__ nbr, int k_vol, int64_t pitch,
     int64_t n_out, const float* __restrict__ w, const float* __restrict__ bias, int relu,
-    float* __restrict__ out) {
-  constexpr int CIN = 4, NT = 1;
-  constexpr int COUT = 32;
-  __shared__ float w_lds[27 * CIN * COUT];   // 13.8 KB: one load per workgroup instead of two dword loads per offset and wave
-  for (int t = threadIdx.x; t < k_vol * CIN * COUT; t += GC_WAVES * 64) w_lds[t] = w[t];
+    float* __restrict__ out, int cout_arg) {
+  constexpr int CIN = 4;
+  const int cout = FULL ? 32 * NT : cout_arg;
+  constexpr int COUT = 32 * NT;   // padded width of the LDS copy
+  __shared__ float w_lds[27 * CIN * COUT];   // 13.8 KB per tile: one load per workgroup instead of two dword loads per offset and wave
+  for (int t = threadIdx.x; t < k_vol * CIN * COUT; t += GC_WAVES * 64) {
+    const int col = t % COUT, rowi = t / COUT;
+    w_lds[t] = col < cout ? w[rowi * cout + col] : 0.f;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
@@ -60,7 +69,12 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
 
   f32x16 acc[NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      acc[t][r] = col < cout ? bias[col] : 0.f;
+    }
 
   const bool row_ok = (row0 + i) < n_out;
   {
@@ -83,11 +97,14 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
       const float4 gc = gq[k % D];
       if (k + D < 27) gq[k % D] = rows_of(nbs[k + D]);  // -1 past k_vol: no load
       if (k < k_vol && __ballot(nbs[k] >= 0) != 0ull) {  // uniform: somebody in this tile has offset k
-        const float wc0 = w_lds[(k * CIN + 0 + h) * COUT + i], wc1 = w_lds[(k * CIN + 2 + h) * COUT + i];
         const float x0 = h ? gc.y : gc.x, x1 = h ? gc.w : gc.z;
-        // transposed product D[co][row] = W^T x X^T: a lane ends up with 16 channels of ONE row (16-B stores below)
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc0, x0, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc1, x1, acc[0], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float wc0 = w_lds[(k * CIN + 0 + h) * COUT + 32 * t + i], wc1 = w_lds[(k * CIN + 2 + h) * COUT + 32 * t + i];
+          // transposed product D[co][row] = W^T x X^T: a lane ends up with 16 channels of ONE row (16-B stores below)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc0, x0, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc1, x1, acc[t], 0, 0, 0);
+        }
       }
     }
   }
@@ -97,13 +114,16 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
   const int64_t g = row0 + i;
   if (g < n_out) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 v = make_float4(acc[0][4 * j], acc[0][4 * j + 1], acc[0][4 * j + 2], acc[0][4 * j + 3]);
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 v = make_float4(acc[t][4 * j], acc[t][4 * j + 1], acc[t][4 * j + 2], acc[t][4 * j + 3]);
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        const int col = 32 * t + 8 * j + 4 * h;
+        if (col < cout) *reinterpret_cast<float4*>(out + g * cout + col) = v;
       }
-      *reinterpret_cast<float4*>(out + g * COUT + 8 * j + 4 * h) = v;
-    }
   }
 }
 
@@ -133,14 +153,17 @@ __global__ __launch_bounds__(256) void k_gconv_scalar(
 
 // generative transposed convolution, kernel 2 stride 2: out[8p+o] = W[o]^T in[p] + b
 // rows (nullable): parent p reads input row rows[p] — the up stage right after a pruning, on the kept rows in place
-template <int NT>
+// CIN: input channels (a multiple of 16); NT: 32-column tiles of the output, cout = any multiple of 16 up to 32 NT (columns
+// beyond cout run on zero weights and are not stored).  <32, 1> and <32, 2> are the model default's shapes.
+// FULL: cout == 32 NT, known at compile time (no column predicate: the weights of an octant are then plain loads the
+// compiler requests together; under a predicate each waited for the one before — 145 -> 238 us on the bench's largest)
+template <int CIN, int NT, bool FULL>
 __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
     const float* __restrict__ in, int64_t n_in, const float* __restrict__ w,
     const float* __restrict__ bias, int relu, float* __restrict__ out,
-    const uint32_t* __restrict__ rows = nullptr) {
-  constexpr int CIN = 32;
-  constexpr int COUT = NT * 32;
+    const uint32_t* __restrict__ rows, int cout_arg) {
   constexpr int PITCH = CIN + 1;
+  const int cout = FULL ? 32 * NT : cout_arg;
   __shared__ float a_lds[GC_WAVES][32 * PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
@@ -148,14 +171,14 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
   const int i = lane & 31, h = lane >> 5;
   float* a = a_lds[wave];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+  for (int it = 0; it < CIN / 8; ++it) {
+    const int idx = it * 64 + lane, r = idx / (CIN / 4), c4 = idx % (CIN / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + r < n_in) {
       const int64_t src = rows ? (int64_t)rows[row0 + r] : row0 + r;
-      v = *reinterpret_cast<const float4*>(in + src * CIN + chunk * 4);
+      v = *reinterpret_cast<const float4*>(in + src * CIN + c4 * 4);
     }
-    float* d = a + r * PITCH + chunk * 4;
+    float* d = a + r * PITCH + c4 * 4;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -166,11 +189,12 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
   for (int s = 0; s < CIN / 2; ++s) av[s] = a[i * PITCH + 2 * s + h];
 
   for (int o = 0; o < 8; ++o) {
-    const float* wo = w + (int64_t)o * CIN * COUT;
+    const float* wo = w + (int64_t)o * CIN * cout;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float b = bias[t * 32 + i];
+      const int colb = t * 32 + i;   // the last column's value stands in beyond cout (never stored)
+      const float b = bias[FULL || colb < cout ? colb : cout - 1];
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = b;
     }
@@ -178,7 +202,8 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
     for (int s = 0; s < CIN / 2; ++s) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float bv = wo[(2 * s + h) * COUT + t * 32 + i];
+        const int colw = t * 32 + i;
+        const float bv = wo[(2 * s + h) * cout + (FULL || colw < cout ? colw : cout - 1)];   // unconditional load
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv, acc[t], 0, 0, 0);
       }
     }
@@ -188,13 +213,46 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_convT_mfma(
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int64_t p = row0 + row;
-        if (p < n_in) {
+        if (p < n_in && (FULL || t * 32 + i < cout)) {
           float v = acc[t][r];
           if (relu) v = fmaxf(v, 0.0f);
-          out[(p * 8 + o) * COUT + t * 32 + i] = v;
+          out[(p * 8 + o) * cout + t * 32 + i] = v;
         }
       }
     }
+  }
+}
+
+template <int CIN>
+static void launch_convT(hipStream_t st, const float* d_in, int64_t n_in, const float* d_w, const float* d_bias, int relu,
+                         float* d_out, const uint32_t* d_rows, int cout) {
+  const dim3 grid(nblk(n_in, 32 * GC_WAVES)), block(GC_WAVES * 64);
+#define PCC_CONVT(NT_)                                                                                                        \
+  if (cout == 32 * NT_)                                                                                                       \
+    hipLaunchKernelGGL((k_convT_mfma<CIN, NT_, true>), grid, block, 0, st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); \
+  else                                                                                                                        \
+    hipLaunchKernelGGL((k_convT_mfma<CIN, NT_, false>), grid, block, 0, st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout)
+  switch ((cout + 31) / 32) {
+    case 1: PCC_CONVT(1); break;
+    case 2: PCC_CONVT(2); break;
+    case 3: PCC_CONVT(3); break;
+    default: PCC_CONVT(4); break;
+  }
+#undef PCC_CONVT
+}
+// widths the matrix-core kernel takes: multiples of 16 up to 128
+static bool convT_widths(int cin, int cout) { return cin % 16 == 0 && cout % 16 == 0 && cin >= 16 && cin <= 128 && cout >= 16 && cout <= 128; }
+static void launch_convT_any(hipStream_t st, const float* d_in, int64_t n_in, const float* d_w, const float* d_bias, int relu,
+                             float* d_out, const uint32_t* d_rows, int cin, int cout) {
+  switch (cin / 16) {
+    case 1: launch_convT<16>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    case 2: launch_convT<32>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    case 3: launch_convT<48>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    case 4: launch_convT<64>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    case 5: launch_convT<80>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    case 6: launch_convT<96>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    case 7: launch_convT<112>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
+    default: launch_convT<128>(st, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, cout); break;
   }
 }
 
@@ -291,6 +349,8 @@ struct PccWeightCache {
   struct Entry {
     float* wsw;
     int k_vol, cout;
+    int cin = 32;   // 32 with the operand order of conv16.h; any other width (or `gen`): the chunked order of convgen.h
+    bool gen = false;
   };
   std::map<const float*, Entry> m;
 };
@@ -308,15 +368,30 @@ static int swizzle_launch(hipStream_t st, const float* d_w, int k_vol, int cout,
   return PCC_OK;
 }
 
+// ---- any widths that are multiples of 16 (convgen.h)
+static int gen_chunk(int cin) { return cin % 32 == 0 ? 32 : 16; }
+static size_t gen_wsw_floats(int k_vol, int cin, int cout) { return (size_t)k_vol * cin * ((cout + 31) / 32) * 32; }
+static bool convgen_widths(int k_vol, int cin, int cout) {
+  return (k_vol == 27 || k_vol == 8) && cin % 16 == 0 && cout % 16 == 0 && cin >= 16 && cin <= 128 && cout >= 16 && cout <= 256;
+}
+static int gen_swizzle_launch(hipStream_t st, const float* d_w, int k_vol, int cin, int cout, float* wsw) {
+  hipLaunchKernelGGL(k_convgen_swizzle, dim3(nblk((int64_t)gen_wsw_floats(k_vol, cin, cout), 256)), dim3(256), 0, st, d_w, k_vol,
+                     cin, cout, gen_chunk(cin), wsw);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 extern "C" int pcc_conv_prepare(pcc_ctx* ctx, const float* d_w, int k_vol, int cin, int cout) {
   PCC_REQUIRE(ctx && d_w, PCC_E_ARG, "pcc_conv_prepare: null argument");
-  PCC_REQUIRE((k_vol == 27 || k_vol == 8) && cin == 32 && (cout == 32 || cout == 64), PCC_E_ARG,
+  const bool tuned = (k_vol == 27 || k_vol == 8) && cin == 32 && (cout == 32 || cout == 64);
+  PCC_REQUIRE(tuned || convgen_widths(k_vol, cin, cout), PCC_E_ARG,
               "pcc_conv_prepare: k_vol=%d cin=%d cout=%d has no pre-arranged form", k_vol, cin, cout);
   if (!ctx->wcache) ctx->wcache = new (std::nothrow) PccWeightCache();
   PCC_REQUIRE(ctx->wcache, PCC_E_NOMEM, "pcc_conv_prepare: out of memory");
   auto it = ctx->wcache->m.find(d_w);
   float* wsw = nullptr;
-  if (it != ctx->wcache->m.end() && it->second.k_vol == k_vol && it->second.cout == cout) {
+  if (it != ctx->wcache->m.end() && it->second.k_vol == k_vol && it->second.cout == cout && it->second.cin == cin &&
+      it->second.gen == !tuned) {
     wsw = it->second.wsw;  // registered before: refresh (the tensor may have new contents)
   } else {
     if (it != ctx->wcache->m.end()) {
@@ -324,10 +399,12 @@ extern "C" int pcc_conv_prepare(pcc_ctx* ctx, const float* d_w, int k_vol, int c
       (void)hipFree(it->second.wsw);
       ctx->wcache->m.erase(it);
     }
-    PCC_HIP(hipMalloc((void**)&wsw, (size_t)k_vol * cout * 32 * 4));
-    ctx->wcache->m[d_w] = {wsw, k_vol, cout};
+    PCC_HIP(hipMalloc((void**)&wsw, tuned ? (size_t)k_vol * cout * 32 * 4 : gen_wsw_floats(k_vol, cin, cout) * 4));
+    PccWeightCache::Entry e;
+    e.wsw = wsw; e.k_vol = k_vol; e.cout = cout; e.cin = cin; e.gen = !tuned;
+    ctx->wcache->m[d_w] = e;
   }
-  return swizzle_launch(ctx->stream, d_w, k_vol, cout, wsw);
+  return tuned ? swizzle_launch(ctx->stream, d_w, k_vol, cout, wsw) : gen_swizzle_launch(ctx->stream, d_w, k_vol, cin, cout, wsw);
 }
 
 extern "C" int pcc_conv_forget(pcc_ctx* ctx, const float* d_w) {
@@ -345,7 +422,7 @@ extern "C" int pcc_conv_forget(pcc_ctx* ctx, const float* d_w) {
 static int weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cout, const float** wsw) {
   if (ctx->wcache) {
     auto it = ctx->wcache->m.find(d_w);
-    if (it != ctx->wcache->m.end() && it->second.k_vol == k_vol && it->second.cout == cout) {
+    if (it != ctx->wcache->m.end() && it->second.k_vol == k_vol && it->second.cout == cout && !it->second.gen) {
       *wsw = it->second.wsw;
       return PCC_OK;
     }
@@ -355,6 +432,25 @@ static int weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cout, cons
   float* tmp = (float*)pcc_arena_alloc(ctx, bytes);
   if (!tmp) return PCC_E_NOMEM;
   PCC_TRY(swizzle_launch(ctx->stream, d_w, k_vol, cout, tmp));
+  *wsw = tmp;
+  return PCC_OK;
+}
+
+// the same for the chunked operand order of convgen.h
+static int gen_weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cin, int cout, const float** wsw) {
+  if (ctx->wcache) {
+    auto it = ctx->wcache->m.find(d_w);
+    if (it != ctx->wcache->m.end() && it->second.k_vol == k_vol && it->second.cout == cout && it->second.cin == cin &&
+        it->second.gen) {
+      *wsw = it->second.wsw;
+      return PCC_OK;
+    }
+  }
+  const size_t bytes = gen_wsw_floats(k_vol, cin, cout) * 4;
+  PCC_TRY(pcc_arena_reserve(ctx, bytes + 512));
+  float* tmp = (float*)pcc_arena_alloc(ctx, bytes);
+  if (!tmp) return PCC_E_NOMEM;
+  PCC_TRY(gen_swizzle_launch(ctx->stream, d_w, k_vol, cin, cout, tmp));
   *wsw = tmp;
   return PCC_OK;
 }
@@ -433,7 +529,7 @@ static int sparse_conv_impl(pcc_ctx* ctx, const float* d_in, int64_t n_in, const
                             const float* d_bias, int cin, int cout, int relu, float* d_out, bool sib) {
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv: null ctx");
   PCC_REQUIRE(k_vol == 27 || k_vol == 8 || k_vol == 1, PCC_E_ARG, "pcc_sparse_conv: k_vol=%d", k_vol);
-  PCC_REQUIRE(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, PCC_E_ARG,
+  PCC_REQUIRE(cin >= 1 && cin <= 128 && cout >= 1 && cout <= 256, PCC_E_ARG,
               "pcc_sparse_conv: cin=%d cout=%d unsupported", cin, cout);
   if (n_out <= 0) return PCC_OK;
   PCC_REQUIRE(d_in && d_nbr && d_w && d_bias && d_out && nbr_pitch >= n_out && n_in > 0, PCC_E_ARG,
@@ -450,10 +546,36 @@ static int sparse_conv_impl(pcc_ctx* ctx, const float* d_in, int64_t n_in, const
       launch16<false, false, false, 32>(st, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
     else
       launch16<false, false, false, 64>(st, d_in, n_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, relu, d_out, nof, nof, nofo);
-  } else if (!sib && !force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 && cout == 32) {
+  } else if (!force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && convgen_widths(k_vol, cin, cout)) {
+    // widths other than the model default's: the chunked kernel (convgen.h); with sib, also 32 -> 32 on an explicit book
+    const float* wsw;
+    PCC_TRY(gen_weights_for(ctx, d_w, k_vol, cin, cout, &wsw));
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
-    hipLaunchKernelGGL(k_gconv_first, dim3(nblk(n_out, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st, d_in, d_nbr, k_vol,
-                       nbr_pitch, n_out, d_w, d_bias, relu, d_out);
+    const dim3 grid((nblk(n_out, 64) + 7) / 8 * 8, (unsigned)((cout + 31) / 32));
+    if (gen_chunk(cin) == 32)
+      hipLaunchKernelGGL((k_gconv_gen<32>), grid, dim3(64), 0, st, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, cin, cout,
+                         relu, sib ? 1 : 0, d_out);
+    else
+      hipLaunchKernelGGL((k_gconv_gen<16>), grid, dim3(64), 0, st, d_in, d_nbr, k_vol, nbr_pitch, n_out, wsw, d_bias, cin, cout,
+                         relu, sib ? 1 : 0, d_out);
+  } else if (!sib && !force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 &&
+             cout % 16 == 0 && cout <= 128) {
+    PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
+    const dim3 grid(nblk(n_out, 32 * GC_WAVES)), block(GC_WAVES * 64);
+#define PCC_FIRST(NT_)                                                                                                          \
+  if (cout == 32 * NT_)                                                                                                         \
+    hipLaunchKernelGGL((k_gconv_first<NT_, true>), grid, block, 0, st, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, \
+                       d_out, cout);                                                                                            \
+  else                                                                                                                          \
+    hipLaunchKernelGGL((k_gconv_first<NT_, false>), grid, block, 0, st, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, \
+                       d_out, cout)
+    switch ((cout + 31) / 32) {
+      case 1: PCC_FIRST(1); break;
+      case 2: PCC_FIRST(2); break;
+      case 3: PCC_FIRST(3); break;
+      default: PCC_FIRST(4); break;
+    }
+#undef PCC_FIRST
   } else {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
     hipLaunchKernelGGL(k_gconv_scalar, dim3(nblk(n_out * cout, 256)), dim3(256), 0, st, d_in, d_nbr,
@@ -559,22 +681,30 @@ int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_
   return PCC_OK;
 }
 
+// which kernel the dispatchers above pick for a shape (16-byte aligned tensors assumed): the tests assert that the widths
+// a model config may name stay on the matrix cores
+extern "C" const char* pcc_conv_kernel_name(int op, int k_vol, int cin, int cout) {
+  if (force_scalar()) return op == 2 ? "k_convT_scalar" : "k_gconv_scalar";
+  if (op == 2) return convT_widths(cin, cout) ? "k_convT_mfma" : "k_convT_scalar";
+  const bool sib = op == 1;
+  if (!sib && cin == 32 && (cout == 32 || cout == 64) && (k_vol == 27 || k_vol == 8)) return "k_gconv16";
+  if (convgen_widths(k_vol, cin, cout)) return "k_gconv_gen";
+  if (!sib && cin == 4 && cout % 16 == 0 && cout <= 128) return "k_gconv_first";
+  return "k_gconv_scalar";
+}
+
 extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, const float* d_w,
                              const float* d_bias, int cin, int cout, int relu, float* d_out) {
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_convT_gen: null ctx");
-  PCC_REQUIRE(cin >= 1 && cin <= 64 && cout >= 1 && cout <= 64, PCC_E_ARG,
+  PCC_REQUIRE(cin >= 1 && cin <= 128 && cout >= 1 && cout <= 256, PCC_E_ARG,
               "pcc_convT_gen: cin=%d cout=%d unsupported", cin, cout);
   if (n_in <= 0) return PCC_OK;
   PCC_REQUIRE(d_in && d_w && d_bias && d_out, PCC_E_ARG, "pcc_convT_gen: null buffers");
   hipStream_t st = ctx->stream;
   PccProfScope prof(ctx, "convT_gen", n_in, cin, cout, 8);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
-  if (!force_scalar() && aligned && cin == 32 && cout == 32) {
-    hipLaunchKernelGGL((k_convT_mfma<1>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
-                       d_in, n_in, d_w, d_bias, relu, d_out, (const uint32_t*)nullptr);
-  } else if (!force_scalar() && aligned && cin == 32 && cout == 64) {
-    hipLaunchKernelGGL((k_convT_mfma<2>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, st,
-                       d_in, n_in, d_w, d_bias, relu, d_out, (const uint32_t*)nullptr);
+  if (!force_scalar() && aligned && convT_widths(cin, cout)) {
+    launch_convT_any(st, d_in, n_in, d_w, d_bias, relu, d_out, nullptr, cin, cout);
   } else {
     hipLaunchKernelGGL(k_convT_scalar, dim3(nblk(n_in * 8 * cout, 256)), dim3(256), 0, st, d_in, n_in,
                        d_w, d_bias, cin, cout, relu, d_out);
@@ -609,8 +739,7 @@ extern "C" int pcc_convT_gen_gather(pcc_ctx* ctx, const float* d_in, const uint3
   PCC_REQUIRE(d_in && d_rows && d_w && d_bias && d_out && (uintptr_t)d_in % 16 == 0, PCC_E_ARG,
               "pcc_convT_gen_gather: null or misaligned buffers");
   PccProfScope prof(ctx, "convT_gen", n_in, 32, 32, 8);
-  hipLaunchKernelGGL((k_convT_mfma<1>), dim3(nblk(n_in, 32 * GC_WAVES)), dim3(GC_WAVES * 64), 0, ctx->stream, d_in,
-                     n_in, d_w, d_bias, relu, d_out, d_rows);
+  launch_convT<32>(ctx->stream, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, 32);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -212,12 +212,21 @@ int pcc_gather_rows_or_zero(pcc_ctx* ctx, const float* d_src,
 
 /* replaces: MinkowskiConvolution forward (3^3 stride 1 with K=27 and a rule
  * book from pcc_build_map; 2^3 stride 2 with K=8 and the rule book from
- * pcc_down_coords).  Supported (cin,cout): (4,32) (32,32) (32,64) on the MFMA
- * path, any (cin<=64, cout<=64) on the scalar-fmaf path (same results). */
+ * pcc_down_coords).  On the matrix cores: cin = 4 or a multiple of 16 up to 128
+ * with cout a multiple of 16 (pcc_conv_kernel_name); any (cin <= 128, cout <= 256)
+ * on the scalar-fmaf path (same results). */
 int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                     const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
                     int64_t n_out, const float* d_w, const float* d_bias,
                     int cin, int cout, int relu, float* d_out);
+/* Diagnostic: name of the kernel pcc_sparse_conv (op 0), the siblings-first conv of
+ * pcc_sparse_conv_head's generic form (op 1) or pcc_convT_gen (op 2) runs for a
+ * shape with 16-byte aligned tensors: "k_gconv16" (32 -> 32 / 64), "k_gconv_gen"
+ * (any widths that are multiples of 16: C_in <= 128, C_out <= 256), "k_gconv_first"
+ * (4 -> multiples of 16), "k_convT_mfma" (multiples of 16 up to 128) — all on the
+ * matrix cores — or the scalar-fmaf kernels ("k_gconv_scalar", "k_convT_scalar":
+ * other shapes, PCC_FORCE_SCALAR=1).  Same results whichever runs. */
+const char* pcc_conv_kernel_name(int op, int k_vol, int cin, int cout);
 /* Layer weights, prepared once.  The (32,32) and (32,64) layers read their weights
  * as matrix-core operands from a copy in operand order (csrc/conv16.h).  A weight
  * tensor [k_vol][cin][cout] registered here — what load_model / model.to(device)

@@ -144,7 +144,7 @@ ORC_API void orc_sparse_conv(const float* in, const int32_t* nbr, int k_vol, int
                              float* out) {
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < n_out; ++r) {
-    float acc[64];
+    float acc[256];
     for (int co = 0; co < cout; ++co) acc[co] = bias[co];
     for (int pass = siblings_first ? 0 : 1; pass < 2; ++pass) {
       for (int k = 0; k < k_vol; ++k) {
@@ -174,7 +174,7 @@ ORC_API void orc_convT_gen(const float* in, int64_t n_in, const float* w, const 
 #pragma omp parallel for schedule(static)
   for (int64_t p = 0; p < n_in; ++p) {
     for (int o = 0; o < 8; ++o) {
-      float acc[64];
+      float acc[256];
       for (int co = 0; co < cout; ++co) acc[co] = bias[co];
       const float* wo = w + (int64_t)o * cin * cout;
       for (int ci = 0; ci < cin; ++ci) {

@@ -292,7 +292,23 @@ def _weights(rng, k, cin, cout):
     return (rng.normal(0, 0.3, (k, cin, cout)).astype(np.float32), rng.normal(0, 0.1, cout).astype(np.float32))
 
 
-@pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (3, 5), (32, 1)])
+WIDTHS = [(16, 16), (64, 64), (32, 128), (48, 80), (128, 32), (16, 256)]    # other model configs: multiples of 16
+
+
+def test_other_widths_stay_on_the_matrix_cores(rt):
+    """the widths a model config may name (ColorModel(config["model"]), codec_pipeline.py:65) are routed to MFMA kernels,
+    not to the scalar fallback; odd shapes and the scalar switch still have one"""
+    name = lambda op, k, ci, co: rt.lib.pcc_conv_kernel_name(op, k, ci, co).decode()   # noqa: E731
+    for ci, co in WIDTHS:
+        assert name(0, 27, ci, co) == "k_gconv_gen" and name(0, 8, ci, co) == "k_gconv_gen" and name(1, 27, ci, co) == "k_gconv_gen"
+        if co <= 128:
+            assert name(2, 8, ci, co) == "k_convT_mfma"
+    assert name(0, 27, 32, 32) == "k_gconv16" and name(0, 8, 32, 64) == "k_gconv16" and name(1, 27, 32, 32) == "k_gconv_gen"
+    assert [name(0, 27, 4, co) for co in (16, 32, 64, 128)] == ["k_gconv_first"] * 4
+    assert name(0, 27, 3, 5) == "k_gconv_scalar" and name(2, 8, 3, 5) == "k_convT_scalar"
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (3, 5), (32, 1), (4, 16), (4, 64), (4, 128)] + WIDTHS)
 @pytest.mark.parametrize("name", ["surf", "tiny", "one"])
 @pytest.mark.parametrize("relu", [False, True])
 def test_sparse_conv3_bit_exact(rt, oracle, clouds, cin, cout, name, relu):
@@ -306,7 +322,7 @@ def test_sparse_conv3_bit_exact(rt, oracle, clouds, cin, cout, name, relu):
     assert np.array_equal(host(out), ref)
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (4, 32)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (4, 32)] + WIDTHS)
 def test_sparse_conv_down_bit_exact(rt, oracle, clouds, cin, cout):
     rng = np.random.default_rng(11)
     keys = sorted_keys(oracle, clouds["surf"])
@@ -369,6 +385,33 @@ def _structured_cloud(kind, n):
         t = np.arange(n) - n // 2
         pts = np.stack([t, t, t], 1)
     return np.concatenate([np.zeros((pts.shape[0], 1), np.int64), pts], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 64), (32, 128), (48, 80)])
+@pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
+@pytest.mark.parametrize("n", [1, 17, 63, 64, 65, 129, 1000])
+def test_conv_other_widths_row_compaction_bit_exact(rt, oracle, kind, n, cin, cout):
+    """k_gconv_gen (convgen.h): window / item boundaries on neighbourhoods from empty to full for widths other than the
+    model default's — chunks of 32 and of 16 input channels, several column blocks, a last block of 16 columns — in
+    plain and in siblings-first order (the g_s layers of such a model: conv + pcc_linear head), against the oracle"""
+    rng = np.random.default_rng(1000 + n + cin)
+    keys = sorted_keys(oracle, _structured_cloud(kind, n))
+    nbr = oracle.map27(keys, 1)
+    x = rng.normal(size=(len(keys), cin)).astype(np.float32)
+    w, b = _weights(rng, 27, cin, cout)
+    out = rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), False)
+    assert np.array_equal(host(out), oracle.sparse_conv(x, nbr, w, b, False))
+    hw = rng.normal(0, 0.3, (cout, 1)).astype(np.float32)
+    hb = rng.normal(0, 0.1, 1).astype(np.float32)
+    feats, logits = rt.sparse_conv_head(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), True, dev(rt, hw), dev(rt, hb))
+    refr = oracle.sparse_conv(x, nbr, w, b, True, siblings_first=True)
+    assert np.array_equal(host(feats), refr)
+    assert np.array_equal(host(logits), oracle.linear(refr, hw, hb)[:, 0])
+    # registered weights give the same bits
+    wd = dev(rt, w)
+    rt.conv_prepare(wd)
+    assert np.array_equal(host(rt.sparse_conv(dev(rt, x), dev(rt, nbr), wd, dev(rt, b), False)), host(out))
+    rt.conv_forget(wd)
 
 
 @pytest.mark.parametrize("kind", ["dense", "dust", "children", "line"])
@@ -588,7 +631,7 @@ def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):
     assert np.array_equal(host(out), ref)
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (5, 3)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (5, 3), (16, 16), (64, 64), (32, 128), (48, 80), (128, 32)])
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 700])
 def test_convT_gen_bit_exact(rt, oracle, cin, cout, n):
     rng = np.random.default_rng(n)

@@ -27,6 +27,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   echo "== SQ pass $n"
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/${P}_sq/p$n -- $B --steps 2 --warmup 1 > $O/${P}_sq_p$n.log 2>&1 || exit 1
 done
-python3 $R/tools/pmc_sq.py $O/${P}_sq "k_gconv16<true, true, true" > $O/${P}_pmc_sq_conv.json
+python3 $R/tools/pmc_sq.py $O/${P}_sq "k_gconv_up<true>" > $O/${P}_pmc_sq_conv.json
 cat $O/${P}_pmc_sq_conv.json | head -40
 cat $O/${P}_bench_line.json | cut -c1-400
