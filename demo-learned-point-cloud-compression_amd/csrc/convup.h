@@ -20,7 +20,7 @@
 //      (issued / useful slots of the remainder 1.45 on 64-row windows, 1.22 on 128-row ones; the whole layer 1.10
 //      against k_gconv16's 1.18 on bench.py's dominant launch, simulated on its geometry).
 //
-// One wave per workgroup, no workgroup barrier.  LDS: 129 accumulator rows x 128 B + two record buffers + book slice = 19.8 KB:
+// One wave per workgroup, no workgroup barrier.  LDS: 129 accumulator rows x 128 B + the slot records + book slice + step table = 19.5 KB:
 // eight waves per CU (two per SIMD), so registers are plentiful (__launch_bounds__(64, 2)).
 //
 // Offsets of the remainder: j = 0 .. 25 <-> k = j + (j >= 13) (the centre offset has no other-parent pair).  An octant
@@ -28,6 +28,34 @@
 // parents); four ride the software pipeline (records, gathered rows and accumulator tiles requested ahead), the rest —
 // windows in densely occupied regions — are contracted at the end of the step without prefetch.
 #pragma once
+
+// Offset step j (k = j + (j >= 13)) and octant o of an output row -> byte (kp | o' << 5): the offset of the parent-level
+// neighbour that holds the row's neighbour (kp, 0 .. 26) and the neighbour's octant o' inside it; kp = 13 where the
+// offset stays inside the row's own parent (siblings: the dense product) and for the steps past the last (row 26).
+struct PccUpLut {
+  unsigned char b[27 * 8];
+};
+__host__ __device__ constexpr PccUpLut pcc_up_lut() {
+  PccUpLut t{};
+  for (int j = 0; j < 27; ++j)
+    for (int o = 0; o < 8; ++o) {
+      int kp = 13, op = 0;
+      if (j < 26) {
+        const int k = j + (j >= 13 ? 1 : 0);
+        const int d[3] = {k / 9 - 1, (k / 3) % 3 - 1, k % 3 - 1}, ob[3] = {(o >> 2) & 1, (o >> 1) & 1, o & 1}, w[3] = {9, 3, 1};
+        kp = 0;
+        for (int a = 0; a < 3; ++a) {
+          const int tt = ob[a] + d[a];   // -1 .. 2
+          kp += ((tt + 2) >> 1) * w[a];
+          op |= (tt & 1) << (2 - a);
+        }
+        if (kp == 13) op = 0;
+      }
+      t.b[j * 8 + o] = (unsigned char)(kp | (op << 5));
+    }
+  return t;
+}
+__device__ const PccUpLut kPccUpLut = pcc_up_lut();
 
 template <bool PERM>
 __global__ __launch_bounds__(64, 2) void k_gconv_up(
@@ -41,16 +69,21 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   constexpr int NJ = 26;             // offsets of the remainder
   __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
   // slot -> (byte offset of the input row, accumulator row address): every lane writes the records of its two rows, a
-  // present row the record of its rank, an absent one a pad record behind the list — all R slots every step, no branch
-  __shared__ __attribute__((aligned(8))) int2 rec[2][R];
+  // present row the record of its rank, an absent one a pad record behind the list — all R slots every step, no branch.
+  // One buffer: the four pipelined items of a step hold their records in registers, the items beyond them read theirs at
+  // the top of the step, before the compaction of the next offset overwrites the list
+  __shared__ __attribute__((aligned(8))) int2 rec[R];
   // the window's slice of the parent rule book, [27][16] (-1: no such parent or neighbour).  Fetched once, in front of the
   // sibling product: the steps of the remainder then issue no load whose latency they cannot plan for — as two dword
   // loads per step straight from the book (44 MB, streamed once: HBM latency) these sat in the in-order load queue in
   // front of the gathers, and every step lasted one such latency (2.4k cycles for 0.5k - 2k cycles of matrix work)
   __shared__ int32_t pb[27 * 16];
+  // kPccUpLut (216 bytes): row 13 of pb is filled with -1 — an offset that stays inside the parent, or lies past the last
+  // step, reads "no neighbour" there, with no compare in the step
+  __shared__ __attribute__((aligned(4))) unsigned char lut[27 * 8];
 
 #ifdef PCCUP_FAT_LDS   // diagnostic: one wave per SIMD (4 workgroups per CU)
-  __shared__ float fat_lds[5200];
+  __shared__ float fat_lds[5000];
   if (in_bytes == 12345u) fat_lds[threadIdx.x] = 1.f;
 #endif
   const int lane = threadIdx.x;
@@ -133,40 +166,22 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     const int e = lane + 64 * i;
     const int64_t pp = par0 + (e & 15);
     pbv[i] = -1;
-    if (e < 27 * 16 && pp < n_par) pbv[i] = nbrp[(int64_t)(e >> 4) * pitch + pp];
+    if (e < 27 * 16 && (e >> 4) != 13 && pp < n_par) pbv[i] = nbrp[(int64_t)(e >> 4) * pitch + pp];
   }
-  auto up_axis = [](int ob, int weight, int opbit) -> uint32_t {   // conv16.h: byte d = parent-offset digit * weight | octant bit << 5
-    uint32_t v = 0u;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const int t = ob + d - 1;
-      v |= (uint32_t)((((t + 2) >> 1) * weight) | ((t & 1) ? (opbit << 5) : 0)) << (8 * d);
-    }
-    return v;
-  };
-  const uint32_t up_x = up_axis((oct >> 2) & 1, 9, 4), up_y = up_axis((oct >> 1) & 1, 3, 2), up_z = up_axis(oct & 1, 1, 1);
-  int32_t nb0 = -1, nb1 = -1;   // rows of the parent-level neighbours of the lane's two parents
+  int32_t nb0 = -1, nb1 = -1;   // rows of the parent-level neighbours of the lane's two parents (-1: none, or a sibling offset)
   uint32_t nb_op7 = 0u;         // octant of the neighbour inside that parent, << 7
-  bool nb_live = false;         // the offset exists and leaves the lane's parent
-  auto request_nb = [&](int j) {
-    const int jj = j < NJ ? j : NJ - 1;
-    const int kk = jj + (jj >= 13 ? 1 : 0);
-    constexpr uint64_t DX = digits3(9), DY = digits3(3), DZ = digits3(1);
-    const uint32_t sh = 2u * (uint32_t)kk;
-    const uint32_t comb = __builtin_amdgcn_ubfe(up_x, ((uint32_t)(DX >> sh) & 3u) << 3, 8u) +
-                          __builtin_amdgcn_ubfe(up_y, ((uint32_t)(DY >> sh) & 3u) << 3, 8u) +
-                          __builtin_amdgcn_ubfe(up_z, ((uint32_t)(DZ >> sh) & 3u) << 3, 8u);
-    const uint32_t kp = comb & 31u;
-    nb_op7 = (comb >> 5) << 7;
-    nb_live = j < NJ && kp != 13u;
-    const int32_t* pr = pb + (kp << 4) + (lane >> 3);
+  uint32_t cb = 13u;            // kPccUpLut byte of the step after the one nb0 / nb1 belong to
+  // two LDS reads in a row, one step apart: the byte of step j, then (next call) the book entries it names
+  auto request_lut = [&](int j) { cb = lut[(j < 26 ? j : 26) * 8 + oct]; };
+  auto request_nb = [&]() {
+    nb_op7 = (cb & 0xE0u) << 2;
+    const int32_t* pr = pb + ((cb & 31u) << 4) + (lane >> 3);
     nb0 = pr[0];
     nb1 = pr[8];
   };
-  // pack the rows that have the requested offset (under another parent) into slot records `b`; returns their count.
-  // Every lane also writes a pad record behind the list (input beyond the buffer, accumulated into the sink row).
-  auto compact = [&](int b) -> int {
-    const bool p0 = nb_live && nb0 >= 0, p1 = nb_live && nb1 >= 0;
+  // pack the rows that have the requested offset (under another parent) into the slot records; returns their count
+  auto compact = [&]() -> int {
+    const bool p0 = nb0 >= 0, p1 = nb1 >= 0;
     const unsigned long long bal0 = __builtin_amdgcn_ballot_w64(p0), bal1 = __builtin_amdgcn_ballot_w64(p1);
     const int c0 = __popcll(bal0), cnt = c0 + __popcll(bal1);
     const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal0, 0u));
@@ -174,8 +189,8 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     // present rows: ranks 0 .. cnt-1 (first rows, then second rows); absent ones: the pads cnt .. R-1 in the same order
     const int s0 = p0 ? r0 : cnt + lane - r0;
     const int s1 = p1 ? c0 + r1 : cnt + 64 - c0 + lane - r1;
-    rec[b][s0] = p0 ? make_int2((int32_t)(((uint32_t)nb0 << 10) | nb_op7), a_own0) : make_int2((int32_t)kPadOff, a_sink);
-    rec[b][s1] = p1 ? make_int2((int32_t)(((uint32_t)nb1 << 10) | nb_op7), a_own1) : make_int2((int32_t)kPadOff, a_sink);
+    rec[s0] = p0 ? make_int2((int32_t)(((uint32_t)nb0 << 10) | nb_op7), a_own0) : make_int2((int32_t)kPadOff, a_sink);
+    rec[s1] = p1 ? make_int2((int32_t)(((uint32_t)nb1 << 10) | nb_op7), a_own1) : make_int2((int32_t)kPadOff, a_sink);
     return cnt;
   };
 #if PCC_CONV_STAMP
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
 #pragma unroll
     for (int i = 0; i < 7; ++i)
       if (lane + 64 * i < 27 * 16) pb[lane + 64 * i] = pbv[i];
+    if (lane < 54) reinterpret_cast<uint32_t*>(lut)[lane] = reinterpret_cast<const uint32_t*>(kPccUpLut.b)[lane];
 #ifdef PCCUP_FAT_LDS
     if (in_bytes == 12345u) acc_lds[lane] = fat_lds[lane ^ 1];
 #endif
@@ -259,10 +275,10 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     const int jj = j < NJ ? j : NJ - 1;
     load_w(W, jj + (jj >= 13 ? 1 : 0));
   };
-  auto read_records = [&](int b, int (&racc)[NI]) {
+  auto read_records = [&](int (&racc)[NI]) {
 #pragma unroll
     for (int g = 0; g < NI; ++g) {
-      const int2 r = rec[b][g * 16 + n];
+      const int2 r = rec[g * 16 + n];
       rin[g] = r.x;
       racc[g] = r.y;
     }
@@ -272,11 +288,18 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
 #else
   auto gather = [&](int g) { load_row((uint32_t)rin[g] | qoff, G[g][0], G[g][1]); };
 #endif
+#ifdef PCCUP_ABL_NO123   // timing ablations: items 1 .. 3 never / all four items always
+#define PCCUP_LIVE(g) (cnt_cur > 16 * (g) + 1000000)
+#elif defined(PCCUP_ABL_ALL4)
+#define PCCUP_LIVE(g) true
+#else
+#define PCCUP_LIVE(g) (cnt_cur > 16 * (g))
+#endif
   int cnt_cur;
   auto step = [&](int j, float4 (&Wc)[4], float4 (&Wn)[4], int (&rc_)[NI], int (&rn)[NI]) {
 #if PCC_CONV_STAMP
     unsigned long long tq[8];
-#define PCCUP_T(i) asm volatile("s_memtime %0" : "=s"(tq[i])::"memory")
+#define PCCUP_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tq[i])::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define PCCUP_T(i) do { } while (0)
 #endif
@@ -284,6 +307,27 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     f32x4 lo0, hi0, lo1, hi1;
     const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
     const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
+    // items beyond the pipeline (more than 64 rows of the window have the offset) first, while the list is still in
+    // LDS: record, rows, tile, chains, one by one (items of one offset touch disjoint rows: their order is free).  The
+    // branch ends with nothing of its own in flight, so the counts of the prefetches stay exact.
+    if (cnt_cur > 16 * NI) {
+      for (int g = NI; 16 * g < cnt_cur; ++g) {
+        const int2 r = rec[g * 16 + n];
+        float4 g0, g1;
+        load_row((uint32_t)r.x | qoff, g0, g1);
+        f32x4 lo, hi;
+        acc_read(r.y, lo, hi);
+        float xv[8];
+        shape(g0, g1, xv);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
+          hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
+        }
+        acc_write(r.y, lo, hi);
+      }
+    }
+    PCCUP_T(6);
     // item 0 is unconditional (pad slots into the sink row when the offset has no row) and carries the bookkeeping of
     // the step between its MFMAs: one basic block (conv16.h)
     acc_read(rc_[0], lo0, hi0);
@@ -292,37 +336,33 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     shape(G[0][0], G[0][1], xv0);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv0[0], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv0[0], hi0, 0, 0, 0);
-    PCCUP_T(1);   // first MFMA pair issued: acc tile + G[0] waits
-    const int cnt_next = compact((j + 1) & 1);
+    const int cnt_next = compact();   // offset j + 1
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[1], xv0[1], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[1], xv0[1], hi0, 0, 0, 0);
-    PCCUP_T(2);   // compaction
-    request_nb(j + 2);
+    request_nb();         // book entries of offset j + 2
+    request_lut(j + 3);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[2], xv0[2], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[2], xv0[2], hi0, 0, 0, 0);
     load_wj(Wn, j + 1);
     lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[3], xv0[3], lo0, 0, 0, 0);
     hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[3], xv0[3], hi0, 0, 0, 0);
-    PCCUP_T(3);   // requests
     PCC16_SYNC();
-    read_records((j + 1) & 1, rn);
+    read_records(rn);
 #pragma unroll
     for (int s = 4; s < 8; ++s) {
       lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv0[s], lo0, 0, 0, 0);
       hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
     }
-    PCCUP_T(4);   // rest of item 0's chains
-    if (cnt_cur <= 16) acc_write(rc_[0], lo0, hi0);
+    if (!PCCUP_LIVE(1)) acc_write(rc_[0], lo0, hi0);
     gather(0);
-    PCCUP_T(5);   // write-back + gather issue (records wait)
-#ifdef PCCUP_ABL_NO123   // timing ablation: items 1 .. 3 are not contracted
-#define PCCUP_LIVE(g) (cnt_cur > 16 * (g) + 1000000)
-#else
-#define PCCUP_LIVE(g) (cnt_cur > 16 * (g))
-#endif
+    PCCUP_T(5);   // item 0 with the bookkeeping
+    // Item g >= 1: [write-back of item g-1 behind the first MFMA pair, tile of item g+1 requested] chains of item g; the
+    // last item of the step writes itself back.  The gathers of the next offset's four items are issued whether or not
+    // the item exists (conv16.h: exact vmcnt counts).  (Four straight-line tails selected by the number of items instead
+    // of a branch around every item were built: 5 % slower.)
 #define PCCUP_ITEM(g, LO, HI, PLO, PHI)                                                                \
-    if (PCCUP_LIVE(g)) {                                                                          \
-      const bool more = (g) + 1 < NI && cnt_cur > 16 * ((g) + 1);                                      \
+    if (PCCUP_LIVE(g)) {                                                                               \
+      const bool more = (g) + 1 < NI && PCCUP_LIVE((g) + 1);                                           \
       float xv[8];                                                                                     \
       shape(G[g][0], G[g][1], xv);                                                                     \
       LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
@@ -340,43 +380,30 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     PCCUP_ITEM(2, lo0, hi0, lo1, hi1);
     PCCUP_ITEM(3, lo1, hi1, lo0, hi0);
 #undef PCCUP_ITEM
-    // items beyond the pipeline (more than 64 rows of the window have the offset): record, rows, tile, chains, one by
-    // one.  The branch ends with nothing of its own in flight, so the counts of the prefetches above stay exact.
-    if (cnt_cur > 16 * NI) {
-      for (int g = NI; 16 * g < cnt_cur; ++g) {
-        const int2 r = rec[j & 1][g * 16 + n];
-        float4 g0, g1;
-        load_row((uint32_t)r.x | qoff, g0, g1);
-        f32x4 lo, hi;
-        acc_read(r.y, lo, hi);
-        float xv[8];
-        shape(g0, g1, xv);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
-          hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
-        }
-        acc_write(r.y, lo, hi);
-      }
-    }
+    PCCUP_T(1);
 #if PCC_CONV_STAMP
-    PCCUP_T(6);   // items 1 .. 3, overflow
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     st_sum[3] += tq[0] - st_last;   // loop back
-    for (int i = 1; i < 7; ++i) st_sum[3 + i] += tq[i] - tq[i - 1];
-    st_last = tq[6];
+    st_sum[8] += tq[6] - tq[0];     // overflow items
+    st_sum[4] += tq[5] - tq[6];     // item 0 + bookkeeping
+    st_sum[5] += tq[1] - tq[5];     // items 1 .. 3, gathers
+    st_sum[9] += (unsigned long long)((cnt_cur + 15) >> 4);   // items of the step
+    st_last = tq[1];
 #endif
     cnt_cur = cnt_next;
   };
 
   // prologue of the remainder: offset 0 compacted and gathered, offset 1 requested
   PCC16_SYNC();
-  request_nb(0);
-  cnt_cur = compact(0);
-  request_nb(1);
+  request_lut(0);
+  request_nb();      // offset 0
+  request_lut(1);
+  cnt_cur = compact();
+  request_nb();      // offset 1
+  request_lut(2);
   load_wj(W0, 0);
   PCC16_SYNC();
-  read_records(0, ra0);
+  read_records(ra0);
 #pragma unroll
   for (int g = 0; g < NI; ++g) gather(g);
 #ifndef PCCUP_NO_IRR
