@@ -197,9 +197,14 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   unsigned long long st_sum[PCC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+  unsigned long long rt0, mt0 = st_last;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
 #endif
 
   // ---- 1. siblings: dense product over the window's 16 parents (slot n = parent par0 + n)
+#ifdef PCCUP_PRIO_DENSE
+  __builtin_amdgcn_s_setprio(PCCUP_PRIO_DENSE);
+#endif
   {
     float xs[8][8];
     {
@@ -393,6 +398,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     cnt_cur = cnt_next;
   };
 
+#ifdef PCCUP_PRIO_IRR
+  __builtin_amdgcn_s_setprio(PCCUP_PRIO_IRR);
+#endif
   // prologue of the remainder: offset 0 compacted and gathered, offset 1 requested
   PCC16_SYNC();
   request_lut(0);
@@ -463,6 +471,11 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     }
   }
 #if PCC_CONV_STAMP
+  {   // shader clock over the wave's life: s_memtime ticks per 100-MHz s_memrealtime tick, x 1000 (st_sum[1] = kHz / 100)
+    unsigned long long rt1, mt1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
+    st_sum[1] = (mt1 - mt0) * 1000ull / (rt1 - rt0 ? rt1 - rt0 : 1ull);
+  }
   if (lane == 0 && blockIdx.x >= 8192 && blockIdx.x < 8192 + 4096) {
     for (int j = 0; j < PCC_NSTAMP; ++j) pcc_stamp_buf[(blockIdx.x - 8192) * PCC_NSTAMP + j] = st_sum[j];
   }

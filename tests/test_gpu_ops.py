@@ -322,15 +322,18 @@ def test_sparse_conv3_bit_exact(rt, oracle, clouds, cin, cout, name, relu):
     assert np.array_equal(host(out), ref)
 
 
+@pytest.mark.parametrize("name", ["surf", "tiny", "one"])
 @pytest.mark.parametrize("cin,cout", [(32, 32), (4, 32)] + WIDTHS)
-def test_sparse_conv_down_bit_exact(rt, oracle, clouds, cin, cout):
+def test_sparse_conv_down_bit_exact(rt, oracle, clouds, cin, cout, name):
+    """the stride-2 kernel-2 layers of g_a / h_a"""
     rng = np.random.default_rng(11)
-    keys = sorted_keys(oracle, clouds["surf"])
+    keys = sorted_keys(oracle, clouds[name])
     pk, nbr8 = oracle.down(keys, 1)
     x = rng.normal(size=(len(keys), cin)).astype(np.float32)
     w, b = _weights(rng, 8, cin, cout)
-    out = rt.sparse_conv(dev(rt, x), dev(rt, nbr8), dev(rt, w), dev(rt, b), True)
-    assert np.array_equal(host(out), oracle.sparse_conv(x, nbr8, w, b, True))
+    for relu in (True, False):
+        out = rt.sparse_conv(dev(rt, x), dev(rt, nbr8), dev(rt, w), dev(rt, b), relu)
+        assert np.array_equal(host(out), oracle.sparse_conv(x, nbr8, w, b, relu))
 
 
 def test_conv_linearity(rt, oracle, clouds):

@@ -18,7 +18,7 @@ PKG = "demo-learned-point-cloud-compression_amd"
 NAMES = ["top", "compact(k+1)", "load_nb(k+2)", "w/slots/gather issue", "acc read", "gather wait+shape",
          "mfma+write", "pre-barrier", "barrier", "tail"]
 if os.environ.get("PCC_CONVUP"):
-    NAMES = ["X loads issued", "-", "wait X + sibling product", "loop back (+ tiles to LDS, prologue)", "tile + G[0] wait, MFMA pair 0",
+    NAMES = ["X loads issued", "(s_memtime ticks per 100-MHz tick x 1000)", "wait X + sibling product", "loop back (+ tiles to LDS, prologue)", "tile + G[0] wait, MFMA pair 0",
              "compaction, MFMA pair 1", "requests, MFMA pairs 2-3", "sync + records issue, MFMA pairs 4-7", "write-back, records wait, gather 0",
              "items 1-3 + overflow"]
 elif os.environ.get("PCC_CONV16"):
