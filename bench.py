@@ -337,15 +337,16 @@ def main():
         # same command, tools/pmc_summary.py); matched by kernel and grid size, else null
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            kname = {"sparse_conv": "k_gconv16", "convT_gen": "k_convT_mfma"}[op]
-            # k_gconv16: one 64-thread workgroup per 64-row window, grid rounded up to a multiple of 8 workgroups
-            # (per-XCD window order); k_convT_mfma: 4 waves x 32 rows
-            grids = (((n_out + 63) // 64 + 7) // 8 * 8 * 64, ((n_out + 127) // 128) * 256)
+            kname = {"sparse_conv": "k_gconv", "convT_gen": "k_convT_mfma"}[op]
+            # k_gconv16: one 64-thread workgroup per 64-row window, k_gconv_up (the g_s layers): one per 128-row window,
+            # grids rounded up to a multiple of 8 workgroups (per-XCD window order); k_convT_mfma: 4 waves x 32 rows
+            grids = (((n_out + 63) // 64 + 7) // 8 * 8 * 64, ((n_out + 127) // 128 + 7) // 8 * 8 * 64,
+                     ((n_out + 127) // 128) * 256)
             recs = [r for r in pmc["kernels"] if kname in r["kernel"] and r["grid_threads"] in grids]
             # the timed (native) engine runs the g_s convs in the form that makes the child rule book in-kernel on
             # channel-permuted rows (<true, true, true, 32>); the PMC passes also hold the explicit-rule-book form
             # from the op-by-op pairs count
-            for tag in ("<true, true, true", "<true, true"):
+            for tag in ("k_gconv_up<true>", "k_gconv_up", "<true, true, true", "<true, true"):
                 hit = [r for r in recs if tag in r["kernel"]]
                 if hit:
                     recs = hit
