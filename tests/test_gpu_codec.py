@@ -313,3 +313,30 @@ def test_second_checkpoint_with_its_own_config(wl, tmp_path, widths, engine):
         oref = oracle.decompress(ref[2])
         for a, b in zip(rec, oref):
             assert np.array_equal(a["points"], b["points"]) and np.array_equal(a["colors"], b["colors"])
+
+
+def test_early_error_leaves_no_upload_in_flight(oracle, wl):
+    """A host-frame encode that fails early (duplicate coordinates: found after the sort, while the colours of a large
+    frame are still crossing PCIe on the codec's upload stream) must not let those DMAs land in pool memory the next
+    call on the same codec reuses: encode-with-error, then a valid encode and a decode on the SAME slot, ten times over,
+    always the oracle's bytes and frames (the upload stream is synchronised before the pool is reset)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    runtime = pkg("runtime")
+    big = wl.room(400_000, seed=21)
+    dup = {"points": np.concatenate([big["points"], big["points"][:1]]),
+           "colors": np.concatenate([big["colors"], big["colors"][:1]])}
+    small = wl.sphere_shell(40, 15.0, seed=22)
+    settings = [[1.0, 0.0], [1, 1]]
+    ref, _ = oracle.compress([small], settings)
+    rec_ref = oracle.decompress(ref[2])
+    e = pkg("codec_pipeline").CompressionPipeline(settings, slots=1)
+    d = pkg("codec_parallel").DecompressionPipeline(slots=1)
+    for _ in range(10):
+        with pytest.raises(runtime.PccError) as err:
+            e.compress(wl.gop([dict(dup)]))
+        assert err.value.code == -4
+        out, _ = e.compress(wl.gop([dict(small)]))
+        assert out[1] == ref[1] and out[2] == ref[2]
+        rec, _ = d.decompress(out[2])
+        assert digest(rec) == digest(rec_ref)
