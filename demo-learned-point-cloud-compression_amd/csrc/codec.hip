@@ -782,6 +782,8 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
     const bool is_up = layer.find(".up") != std::string::npos;
     // every conv layer whose widths have a matrix-core form (the model default's 32 -> 32 / 64, and any other multiples of
     // 16 a config.yaml may name: pcc_conv_kernel_name)
+    if (is_up && t.dims[0] == 8 && t.dims[1] == 32 && t.dims[2] == 32 && cd->dev.count(k))
+      (void)pcc_conv_prepare(ctx, cd->dev[k], 8, 32, 32);   // k_convT16 (a failure leaves the per-call copy)
     if (!is_up && (t.dims[0] == 27 || t.dims[0] == 8) && t.dims[1] % 16 == 0 && t.dims[2] % 16 == 0 && t.dims[1] <= 128 &&
         t.dims[2] <= 256 && cd->dev.count(k)) {
       if (pcc_conv_prepare(ctx, cd->dev[k], (int)t.dims[0], (int)t.dims[1], (int)t.dims[2]) != PCC_OK) {
@@ -812,6 +814,7 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
       }
       cd->dev[layer + ".weight#perm"] = dw;
       cd->dev[layer + ".bias#perm"] = db;
+      (void)pcc_conv_prepare(ctx, dw, 8, 32, 32);   // k_convT16 reads the up stage's weights in operand order too
     }
   }
   static const char* need[] = {"g_a.conv0.weight", "g_a.conv3.weight", "h_a.conv0.weight", "h_s.conv0.weight",

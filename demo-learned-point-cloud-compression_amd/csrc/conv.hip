@@ -256,6 +256,99 @@ static void launch_convT_any(hipStream_t st, const float* d_in, int64_t n_in, co
   }
 }
 
+// The model default's up stage (32 -> 32) on the transposed 16-slot product of conv16.h: a wave takes 16 parents, holds
+// their rows as MFMA B operands (two 16-B loads per lane, once), and per octant runs two chains of eight
+// v_mfma_f32_16x16x4_f32 on the operand-ordered weights (four coalesced 16-B loads per lane and octant, requested an octant
+// ahead), turns the tile through 2 KB of LDS and stores it as whole 128-B rows, 16 B per lane, with raw buffer stores (a
+// row of a parent past the end lies beyond the buffer and is dropped: no branch around a store, so the compiler's vmcnt
+// counts stay exact — under `if (row exists) store` every octant waited for the previous one's stores to be acknowledged).
+// k_convT_mfma<32, 1> wrote the same rows with 4-B stores, sixteen store instructions per octant behind a chain of sixteen
+// dependent 32x32x2 MFMAs whose B operands were 4-B loads; chains and stores took turns inside a wave (83 us without the
+// stores, 84 us without the chains, 158 us together for the 408k -> 3.26M stage isolated; a plain fill of the same 417 MB
+// takes 63 us).  This kernel: 135 us there, 33 us (was 51) for 106k -> 846k.  A variant with the weights in LDS (one copy
+// per 256-thread workgroup, 8 tiles per wave, no global load inside a tile but the next tile's rows) was built: the
+// same 134 us at the large size, slower at the small ones (few workgroups); its parts alone — 116 us without the
+// chains, 100 us without the stores — say the limit is neither the weight loads nor the order of loads and stores.
+__global__ __launch_bounds__(64) void k_convT16(
+    const float* __restrict__ in, int64_t n_in, const float* __restrict__ wsw, const float* __restrict__ bias, int relu,
+    float* __restrict__ out, const uint32_t* __restrict__ rows) {
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(uint32_t)(n_in * 1024), 0x00027000);
+  __shared__ __attribute__((aligned(16))) float tile[2][2][16 * 16];   // [buffer][plane][row][16]: the layout of conv16.h's accumulators
+  const int lane = threadIdx.x, n = lane & 15, q = lane >> 4, grow = lane >> 3, chunk = lane & 7;
+  const int64_t p0 = (int64_t)blockIdx.x * 16;
+  if (p0 >= n_in) return;
+  const int64_t p = p0 + n;
+  float xv[8];
+  {
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    if (p < n_in) {
+      const int64_t src = rows ? (int64_t)rows[p] : p;
+      const float4* xp = reinterpret_cast<const float4*>(in + src * 32 + q * 8);
+      g0 = xp[0];
+      g1 = xp[1];
+    }
+    unsigned m[2][4] = {{__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)},
+                        {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)}};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {   // conv16.h, natural rows: 4 x 4 transposes among the q-lanes of a slot
+      u32x2 t = __builtin_amdgcn_permlane32_swap(m[b][0], m[b][2], false, false);
+      m[b][0] = t[0]; m[b][2] = t[1];
+      t = __builtin_amdgcn_permlane32_swap(m[b][1], m[b][3], false, false);
+      m[b][1] = t[0]; m[b][3] = t[1];
+      t = __builtin_amdgcn_permlane16_swap(m[b][0], m[b][1], false, false);
+      m[b][0] = t[0]; m[b][1] = t[1];
+      t = __builtin_amdgcn_permlane16_swap(m[b][2], m[b][3], false, false);
+      m[b][2] = t[0]; m[b][3] = t[1];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) xv[2 * t4 + b] = __uint_as_float(m[b][t4]);
+    }
+  }
+  const float* bp = bias + 4 * q;
+  const f32x4 bl = {bp[0], bp[1], bp[2], bp[3]}, bh = {bp[16], bp[17], bp[18], bp[19]};
+  auto load_w = [&](float4 (&W)[4], int o) {
+    const float4* wp = reinterpret_cast<const float4*>(wsw + (int64_t)(o < 8 ? o : 7) * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[j] = wp[j];
+  };
+  float4 Wa[4], Wb[4];
+  load_w(Wa, 0);
+  auto octant = [&](int o, const float4 (&W)[4], float4 (&Wn)[4]) {
+    load_w(Wn, o + 1);
+    const float wl[8] = {W[0].x, W[0].y, W[0].z, W[0].w, W[1].x, W[1].y, W[1].z, W[1].w};
+    const float wh[8] = {W[2].x, W[2].y, W[2].z, W[2].w, W[3].x, W[3].y, W[3].z, W[3].w};
+    f32x4 lo = bl, hi = bh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
+      hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
+    }
+    float4 a = make_float4(lo[0], lo[1], lo[2], lo[3]), b = make_float4(hi[0], hi[1], hi[2], hi[3]);
+    if (relu) {
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+      b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+    }
+    float (&T)[2][16 * 16] = tile[o & 1];
+    // lane (n, q) holds channels 4q .. of row n in plane 0 and 16 + 4q .. in plane 1
+    *reinterpret_cast<float4*>(&T[0][n * 16 + 4 * q]) = a;
+    *reinterpret_cast<float4*>(&T[1][n * 16 + 4 * q]) = b;
+    PCC16_SYNC();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {   // lane (grow, chunk): piece `chunk` (4 channels) of rows grow and grow + 8
+      const int r = grow + 8 * it;
+      const float4 v = *reinterpret_cast<const float4*>(&T[chunk >> 2][r * 16 + 4 * (chunk & 3)]);
+      const uint32_t off = (uint32_t)(((p0 + r) * 8 + o) * 128 + 16 * chunk);   // beyond the buffer for a parent past the end
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(bits, out_rs, off, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int o = 0; o < 8; o += 2) {
+    octant(o, Wa, Wb);
+    octant(o + 1, Wb, Wa);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_convT_scalar(
     const float* __restrict__ in, int64_t n_in, const float* __restrict__ w,
     const float* __restrict__ bias, int cin, int cout, int relu, float* __restrict__ out) {
@@ -519,6 +612,16 @@ static void launch_up(hipStream_t st, const float* d_in, int64_t n_parents, cons
   }
 }
 
+// PCC_CONVT_LEGACY=1 in the environment (read once): the 32 -> 32 up stages stay on k_convT_mfma<32, 1> (cross-check)
+static bool convT_legacy() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PCC_CONVT_LEGACY");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 static bool conv16_shape(const float* d_in, const float* d_out, int k_vol, int cin, int cout) {
   return !force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 32 &&
          (cout == 32 || cout == 64) && (k_vol == 27 || k_vol == 8);
@@ -685,6 +788,7 @@ int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_
 // a model config may name stay on the matrix cores
 extern "C" const char* pcc_conv_kernel_name(int op, int k_vol, int cin, int cout) {
   if (force_scalar()) return op == 2 ? "k_convT_scalar" : "k_gconv_scalar";
+  if (op == 2 && cin == 32 && cout == 32 && !convT_legacy()) return "k_convT16";
   if (op == 2) return convT_widths(cin, cout) ? "k_convT_mfma" : "k_convT_scalar";
   const bool sib = op == 1;
   if (!sib && cin == 32 && (cout == 32 || cout == 64) && (k_vol == 27 || k_vol == 8)) return "k_gconv16";
@@ -703,7 +807,13 @@ extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, cons
   hipStream_t st = ctx->stream;
   PccProfScope prof(ctx, "convT_gen", n_in, cin, cout, 8);
   const bool aligned = ((uintptr_t)d_in % 16 == 0);
-  if (!force_scalar() && aligned && convT_widths(cin, cout)) {
+  if (!force_scalar() && aligned && cin == 32 && cout == 32 && (uintptr_t)d_out % 16 == 0 && n_in < ((int64_t)1 << 22) &&
+      !convT_legacy()) {
+    const float* wsw;
+    PCC_TRY(weights_for(ctx, d_w, 8, 32, &wsw));
+    hipLaunchKernelGGL(k_convT16, dim3(nblk(n_in, 16)), dim3(64), 0, st, d_in, n_in, wsw, d_bias, relu, d_out,
+                       (const uint32_t*)nullptr);
+  } else if (!force_scalar() && aligned && convT_widths(cin, cout)) {
     launch_convT_any(st, d_in, n_in, d_w, d_bias, relu, d_out, nullptr, cin, cout);
   } else {
     hipLaunchKernelGGL(k_convT_scalar, dim3(nblk(n_in * 8 * cout, 256)), dim3(256), 0, st, d_in, n_in,
@@ -739,7 +849,13 @@ extern "C" int pcc_convT_gen_gather(pcc_ctx* ctx, const float* d_in, const uint3
   PCC_REQUIRE(d_in && d_rows && d_w && d_bias && d_out && (uintptr_t)d_in % 16 == 0, PCC_E_ARG,
               "pcc_convT_gen_gather: null or misaligned buffers");
   PccProfScope prof(ctx, "convT_gen", n_in, 32, 32, 8);
-  launch_convT<32>(ctx->stream, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, 32);
+  if ((uintptr_t)d_out % 16 == 0 && n_in < ((int64_t)1 << 22) && !convT_legacy()) {
+    const float* wsw;
+    PCC_TRY(weights_for(ctx, d_w, 8, 32, &wsw));
+    hipLaunchKernelGGL(k_convT16, dim3(nblk(n_in, 16)), dim3(64), 0, ctx->stream, d_in, n_in, wsw, d_bias, relu, d_out, d_rows);
+  } else {
+    launch_convT<32>(ctx->stream, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, 32);
+  }
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -223,7 +223,8 @@ int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
  * pcc_sparse_conv_head's generic form (op 1) or pcc_convT_gen (op 2) runs for a
  * shape with 16-byte aligned tensors: "k_gconv16" (32 -> 32 / 64), "k_gconv_gen"
  * (any widths that are multiples of 16: C_in <= 128, C_out <= 256), "k_gconv_first"
- * (4 -> multiples of 16), "k_convT_mfma" (multiples of 16 up to 128) — all on the
+ * (4 -> multiples of 16), "k_convT16" (the up stage 32 -> 32), "k_convT_mfma" (other
+ * multiples of 16 up to 128) — all on the
  * matrix cores — or the scalar-fmaf kernels ("k_gconv_scalar", "k_convT_scalar":
  * other shapes, PCC_FORCE_SCALAR=1).  Same results whichever runs. */
 const char* pcc_conv_kernel_name(int op, int k_vol, int cin, int cout);

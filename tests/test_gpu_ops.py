@@ -306,6 +306,7 @@ def test_other_widths_stay_on_the_matrix_cores(rt):
     assert name(0, 27, 32, 32) == "k_gconv16" and name(0, 8, 32, 64) == "k_gconv16" and name(1, 27, 32, 32) == "k_gconv_gen"
     assert [name(0, 27, 4, co) for co in (16, 32, 64, 128)] == ["k_gconv_first"] * 4
     assert name(0, 27, 3, 5) == "k_gconv_scalar" and name(2, 8, 3, 5) == "k_convT_scalar"
+    assert name(2, 8, 32, 32) == "k_convT16" and name(2, 8, 32, 64) == "k_convT_mfma"
 
 
 @pytest.mark.parametrize("cin,cout", [(4, 32), (32, 32), (32, 64), (3, 5), (32, 1), (4, 16), (4, 64), (4, 128)] + WIDTHS)
@@ -635,7 +636,7 @@ def test_conv32_rule_book_with_pitch_and_foreign_input(rt, oracle):
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (5, 3), (16, 16), (64, 64), (32, 128), (48, 80), (128, 32)])
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 700])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 31, 32, 33, 700])
 def test_convT_gen_bit_exact(rt, oracle, cin, cout, n):
     rng = np.random.default_rng(n)
     x = rng.normal(size=(n, cin)).astype(np.float32)
