@@ -120,9 +120,11 @@ __global__ __launch_bounds__(64) void k_gconv16(
   static_assert(R == 64 || R == 32, "window of 64 or 32 rows");
   // Accumulators in LDS: two planes (channels 0..15, 16..31) of 16-float rows; the 16-B piece q of a row sits at
   // position (q + 2 (row >> 2)) & 3 of its plane row.  The hardware serves a ds_read_b128 / ds_write_b128 in groups of 16
-  // lanes that hold 16 different slots and two values of q; with a plain row-major layout (any pitch) consecutive rows
-  // then collide pairwise (SQ_LDS_BANK_CONFLICT was 40 % of SQ_LDS_IDX_ACTIVE), with this placement an item of 16
-  // consecutive rows is conflict-free and compacted row lists collide only by chance.
+  // lanes that hold 16 different slots and two values of q.  The placement makes an item of 16 CONSECUTIVE rows
+  // conflict-free; the rows of a compacted list are not consecutive, and the counters say so: SQ_LDS_BANK_CONFLICT /
+  // SQ_LDS_IDX_ACTIVE = 52 % for this kernel (profiles/r02q_pmc_sq_conv.json), 58 % for k_gconv_up, which uses the same
+  // placement (profiles/r03p_pmc_sq_conv.json) — any fixed placement leaves 16 arbitrary rows to collide by chance.  It is
+  // not what limits either kernel (no accumulator traffic at all: no gain).
   constexpr int HP = (R + 1) * 16;   // floats per plane (row R = sink of the pad slots)
   constexpr int NI = R / 16;   // items an offset can have
   __shared__ __attribute__((aligned(16))) float acc_lds[2 * HP];
