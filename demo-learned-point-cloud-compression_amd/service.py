@@ -21,16 +21,16 @@ import numpy as np
 
 # ------------------------------------------------------------------ sender side
 def sample(batch, segment_duration, target_fps):
-    """Uniformly sample n = segment_duration*target_fps frames by nearest capture timestamp
-    (encoder.py:95-129).  Pops "timestamp" from the chosen frames like the reference does."""
-    timestamps = [item["timestamp"] for item in batch]
-    start_time = timestamps[0]
+    """The GOP the encoder service hands to compress() (sender/encoder/encoder.py:95-129): of the frames captured during
+    one segment, the n = segment_duration * target_fps whose capture times lie nearest to n equally spaced instants from
+    the first frame's on (the earliest frame wins a tie; one frame may serve two instants).  The chosen frames lose their
+    "timestamp" key, which moves into the GOP's timestamps — as the reference does it."""
+    stamps = np.asarray([frame["timestamp"] for frame in batch], dtype=np.float64)
     n = int(segment_duration * target_fps)
-    step = segment_duration / n
-    targets = [start_time + i * step for i in range(n)]
-    sampled = [min(batch, key=lambda item: abs(item["timestamp"] - t)) for t in targets]
-    sampled_timestamps = [frame.pop("timestamp") for frame in sampled]
-    return {"frames": sampled, "timestamps": {"capturing": sampled_timestamps, "sampling": time.time()}}
+    instants = stamps[0] + np.arange(n, dtype=np.float64) * (segment_duration / n)
+    nearest = np.abs(stamps[None, :] - instants[:, None]).argmin(axis=1)       # first minimum = the reference's min()
+    frames = [batch[i] for i in nearest]
+    return {"frames": frames, "timestamps": {"capturing": [f.pop("timestamp") for f in frames], "sampling": time.time()}}
 
 
 def compress_batch(codec, gop, segment_duration, target_fps):
