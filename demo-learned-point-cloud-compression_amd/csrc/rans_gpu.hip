@@ -6,11 +6,14 @@
 // (sender/encoder/codec_pipeline.py:305-306,426-430; receiver/decoder/codec_parallel.py:307,398-400).  The
 // reference's stream is ONE rANS state over the channel-major [C, N] symbols: serial by construction, 2.0 ms to encode
 // and 2.3 ms to decode per quality of a 1M-point frame on a host core, with the GPU idle meanwhile and a PCIe round trip
-// of the symbols around it.  Here the arithmetic of a coding step is unchanged (64-bit state, L = 2^31, 32-bit
-// renormalisation words, 16-bit CDFs, the escape bin followed by 4-bit bypass nibbles — pcc_oracle.c:326 restates it)
-// but the symbols are dealt to 64 independent states per wave:
+// of the symbols around it.  Here the coding step is the same rANS step on the same 16-bit CDFs with the same escape bin
+// followed by 4-bit bypass nibbles, on a state half as wide — 32 bits, L = 2^16, 16-bit renormalisation words (round 3;
+// rounds 1-2 kept CompressAI's 64-bit state: 8 bytes of final state per lane and chunk, which priced chunks of 64 x 512
+// symbols at +4.5 % rate; a state of 32 bits flushes 4 bytes, so chunks of 64 x 256 cost the same rate and a launch —
+// which lasts as long as one chunk — half the steps, each of them 32-bit arithmetic) — and the symbols are dealt to 64
+// independent states per wave:
 //
-//   stream  = u32 'PCI1' | u32 n | u32 T | u32 n_chunks | u32 words[n_chunks] | chunk payloads
+//   stream  = u32 'PCI2' | u32 n | u32 T | u32 n_chunks | u32 words[n_chunks] | chunk payloads (16-bit words)
 //   chunk c = symbols [c 64 T, (c+1) 64 T): step t of lane l codes symbol c 64 T + 64 t + l (coalesced)
 //   payload = 64 x (state lo, state hi) | block(step 0, round 0) | block(0, 1) .. | block(1, 0) ..
 //   round 0 of a step is the symbol's bin, rounds 1.. are the bypass nibbles of the lanes whose symbol escaped;
@@ -22,13 +25,13 @@
 // and a symbol is found by binary search there.  All integer: bit-exact against oracle/pcc_oracle.c
 // (orc_rans_interleaved_*), which restates the same order sequentially.
 //
-// Time: a launch lasts as long as ONE chunk — T sequential steps of one wave alone on its SIMD, ~0.66 us each: 150-200
-// dependent instructions (64-bit integer arithmetic in 32-bit pieces, ballots, the f64 reciprocal product) at the ~8
-// cycles a lone wave gets per dependent instruction.  What is NOT on that chain any more: the symbol / index loads (eight
+// Time: a launch lasts as long as ONE chunk — T sequential steps of one wave alone on its SIMD (rounds 1-2: ~0.66 us per
+// step of 64-bit arithmetic in 32-bit pieces; measured figures of this form in DESIGN.md §6b) at the ~8 cycles a lone wave
+// gets per dependent instruction.  What is NOT on that chain any more: the symbol / index loads (eight
 // steps in flight), the encoder's table lookups and 1 / freq (done one step ahead), the decoder's stream words (128 of
 // them in two registers per lane, refilled 64 words before they are needed).  Measured and dropped: 256 buckets with a
 // four-entry resolve instead of 64 buckets + binary search in the decoder (two dependent LDS reads instead of four to
-// five: 0.36 -> 0.42 ms, more instructions).  Shorter chunks buy time with rate (512 B of final states per chunk).
+// five: 0.36 -> 0.42 ms, more instructions).  Shorter chunks buy time with rate (256 B of final states per chunk).
 #include "common.h"
 
 #include <string.h>
@@ -39,8 +42,8 @@
 
 namespace {
 
-constexpr uint32_t kMagic = 0x31494350u;  // "PCI1" little-endian
-constexpr uint64_t kL = 1ull << 31;
+constexpr uint32_t kMagic = 0x32494350u;  // "PCI2" little-endian
+constexpr uint32_t kL = 1u << 16;         // 32-bit states, 16-bit renormalisation words
 constexpr int kLanes = 64;
 constexpr int kChunksPerWg = 4;
 constexpr int kHeaderWords = 4;
@@ -122,19 +125,20 @@ extern "C" void pcc_rans_dev_destroy(pcc_rans_dev* t) {
 }
 
 // steps per chunk for an array of n symbols.  A launch lasts as long as ONE chunk (its steps are sequential), and every
-// chunk costs 512 B of final states: whole arrays of up to 32768 symbols are one chunk; up to 262144 symbols (the z
-// string of a large GOP, the y string of a small one) chunks of 64 x 128; above, chunks of 64 x 512 (5 % of a 2-bit-per-
-// symbol stream)
+// chunk costs 256 B of final states: whole arrays of up to 32768 symbols are one chunk; up to 262144 symbols (the z
+// string of a large GOP, the y string of a small one) chunks of 64 x 80; above, chunks of 64 x 320: +4.4 % on the
+// 1M-point frame's y strings (2.4 bits per symbol), of which 0.5 % is the narrow state's coding loss (L equals the
+// 16-bit probability scale); measured on that frame: T = 256: +5.3 %, 0.21 ms per direction; T = 384: +3.7 %, 0.30 ms
 static inline int64_t steps_for(int64_t n) {
-  return n > 262144 ? 512 : n > 32768 ? 128 : std::max<int64_t>((n + kLanes - 1) / kLanes, 1);
+  return n > 262144 ? 320 : n > 32768 ? 80 : std::max<int64_t>((n + kLanes - 1) / kLanes, 1);
 }
 static inline int64_t chunks_for(int64_t n, int64_t T) { return std::max<int64_t>((n + kLanes * T - 1) / (kLanes * T), 1); }
 
 extern "C" int64_t pcc_rans_dev_bound(int64_t n) {
   if (n < 0) return 0;
   const int64_t T = steps_for(n), nc = chunks_for(n, T);
-  // header + per chunk: states + up to one word per coding round (a symbol that escapes has up to 10 rounds)
-  return 4 * (kHeaderWords + nc + nc * (2 * kLanes + kLanes * T * 11));
+  // header + per chunk: states + up to one 16-bit word per coding round (a symbol that escapes has up to 10 rounds)
+  return 4 * (kHeaderWords + nc) + 2 * (nc * (2 * kLanes + kLanes * T * 11)) + 4;
 }
 
 // ---- shared device pieces -------------------------------------------------------------------------------------
@@ -171,7 +175,7 @@ static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_
 // words_out[s * n_chunks + c] = words of the chunk (0xFFFFFFFF: the buffer was too small).
 __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __restrict__ sym,
                                                   const uint8_t* __restrict__ idx, int64_t idx_run, int64_t n,
-                                                  int64_t T, int64_t n_chunks, uint32_t* __restrict__ work,
+                                                  int64_t T, int64_t n_chunks, uint16_t* __restrict__ work,
                                                   int64_t cap_words, uint32_t* __restrict__ words_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   uint16_t* s_cdf = reinterpret_cast<uint16_t*>(s_raw);
@@ -183,10 +187,10 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
   if (c >= n_chunks) return;
   const int32_t* ssym = sym + s * n;
   const uint8_t* sidx = idx ? idx + s * n : nullptr;
-  uint32_t* buf = work + (s * n_chunks + c) * cap_words;
-  int64_t ptr = cap_words;   // words [ptr, cap_words) are written
+  uint16_t* buf = work + (s * n_chunks + c) * cap_words;
+  int64_t ptr = cap_words;   // 16-bit words [ptr, cap_words) are written
   bool overflow = false;
-  uint64_t x = kL;
+  uint32_t x = kL;
   const int64_t base = c * kLanes * T;
 
   // symbol and table index of the step after this one are requested before this step's arithmetic
@@ -260,17 +264,17 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
       for (int r = 9; r >= 1; --r) {
         const bool in = esc && r <= 1 + nb;
         if (__ballot(in) == 0ull) continue;
-        const bool need = in && x >= (1ull << 59);   // ((L >> 16) << 32) * 2^12
+        const bool need = in && x >= (1u << 28);   // ((L >> 16) << 16) * 2^12
         const unsigned long long bal = __ballot(need);
         const int cnt = __popcll(bal);
         if (cnt) {
           if (ptr - cnt < 2 * kLanes) overflow = true;
           else {
             ptr -= cnt;
-            if (need) buf[ptr + lane_rank(bal)] = (uint32_t)x;
+            if (need) buf[ptr + lane_rank(bal)] = (uint16_t)x;
           }
         }
-        if (need) x >>= 32;
+        if (need) x >>= 16;
         if (in) {
           const uint32_t val = r == 1 ? (uint32_t)nb : (raw >> (4 * (r - 2))) & 15u;
           x = (x << 4) | val;
@@ -278,27 +282,26 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
       }
     }
     {  // round 0: the symbol's bin
-      const bool need = act && x >= ((uint64_t)(uint32_t)freq << 47);   // ((L >> 16) << 32) * freq
+      const bool need = act && (uint64_t)x >= ((uint64_t)(uint32_t)freq << 16);   // ((L >> 16) << 16) * freq (freq may be 2^16)
       const unsigned long long bal = __ballot(need);
       const int cnt = __popcll(bal);
       if (cnt) {
         if (ptr - cnt < 2 * kLanes) overflow = true;
         else {
           ptr -= cnt;
-          if (need) buf[ptr + lane_rank(bal)] = (uint32_t)x;
+          if (need) buf[ptr + lane_rank(bal)] = (uint16_t)x;
         }
       }
-      if (need) x >>= 32;
+      if (need) x >>= 16;
       if (act) {
-        // x / freq, x % freq with x < 2^47 freq: the quotient from one multiplication by 1 / freq in double (x and the
-        // reciprocal are each within 2^-52 of exact and the quotient is below 2^47: off by at most one), corrected by
-        // the remainder — no division routine and no division on the chain from state to state
-        const uint64_t f = (uint32_t)freq;
-        uint64_t qd = (uint64_t)((double)x * cur.rinv);
-        int64_t rem = (int64_t)(x - qd * f);
+        // x / freq, x % freq with x < 2^16 freq: the quotient from one multiplication by 1 / freq in double (exact operands,
+        // quotient below 2^16: off by at most one), corrected by the remainder — no division on the chain from state to state
+        const uint32_t f = (uint32_t)freq;
+        uint32_t qd = (uint32_t)((double)x * cur.rinv);
+        int64_t rem = (int64_t)x - (int64_t)qd * f;
         if (rem < 0) { --qd; rem += (int64_t)f; }
         else if (rem >= (int64_t)f) { ++qd; rem -= (int64_t)f; }
-        x = (qd << 16) + (uint64_t)rem + (uint32_t)start;
+        x = (qd << 16) + (uint32_t)rem + (uint32_t)start;
       }
     }
     cur = nxt;
@@ -306,15 +309,15 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
   }
   if (!overflow) {
     ptr -= 2 * kLanes;
-    buf[ptr + 2 * lane] = (uint32_t)x;
-    buf[ptr + 2 * lane + 1] = (uint32_t)(x >> 32);
+    buf[ptr + 2 * lane] = (uint16_t)x;
+    buf[ptr + 2 * lane + 1] = (uint16_t)(x >> 16);
   }
   if (lane == 0) words_out[s * n_chunks + c] = overflow ? 0xFFFFFFFFu : (uint32_t)(cap_words - ptr);
 }
 
 // header + chunk table + payloads of every stream, packed: workgroup (c, s) moves chunk c of stream s (c == n_chunks:
 // writes the header); len_out[s] = bytes of stream s, or -1 when a chunk overflowed its buffer
-__global__ __launch_bounds__(256) void k_rans_pack(const uint32_t* __restrict__ work, int64_t cap_words,
+__global__ __launch_bounds__(256) void k_rans_pack(const uint16_t* __restrict__ work, int64_t cap_words,
                                                    const uint32_t* __restrict__ words, int64_t n, int64_t T,
                                                    int64_t n_chunks, uint8_t* __restrict__ out, int64_t cap_each,
                                                    long long* __restrict__ len_out) {
@@ -343,9 +346,9 @@ __global__ __launch_bounds__(256) void k_rans_pack(const uint32_t* __restrict__ 
   uint32_t* o = reinterpret_cast<uint32_t*>(out + s * cap_each);
   const unsigned long long head = kHeaderWords + (unsigned long long)n_chunks;
   if (c == n_chunks) {
-    const unsigned long long total = head + before;
-    const bool fits = !bad && (long long)(total * 4) <= cap_each;
-    if (threadIdx.x == 0) len_out[s] = fits ? (long long)(total * 4) : -1;
+    const unsigned long long total = head * 4 + before * 2;   // bytes: u32 header and chunk table, 16-bit payload words
+    const bool fits = !bad && (long long)total <= cap_each;
+    if (threadIdx.x == 0) len_out[s] = fits ? (long long)total : -1;
     if (!fits) return;
     if (threadIdx.x == 0) {
       o[0] = kMagic;
@@ -358,9 +361,9 @@ __global__ __launch_bounds__(256) void k_rans_pack(const uint32_t* __restrict__ 
   }
   if (bad) return;
   const uint32_t cw = w[c];
-  if ((long long)((head + before + cw) * 4) > cap_each) return;   // the header block reports it
-  const uint32_t* src = work + (s * n_chunks + c) * cap_words + (cap_words - cw);
-  uint32_t* dst = o + head + before;
+  if ((long long)(head * 4 + (before + cw) * 2) > cap_each) return;   // the header block reports it
+  const uint16_t* src = work + (s * n_chunks + c) * cap_words + (cap_words - cw);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(o + head) + before;
   for (uint32_t j = threadIdx.x; j < cw; j += blockDim.x) dst[j] = src[j];
 }
 
@@ -383,13 +386,13 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   for (int64_t j = lane; j < c; j += kLanes) before += in[kHeaderWords + j];
   for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
   const uint32_t cw = in[kHeaderWords + c];
-  const uint32_t* p = in + kHeaderWords + n_chunks + before;
+  const uint16_t* p = reinterpret_cast<const uint16_t*>(in + kHeaderWords + n_chunks) + before;
   int bad = 0;
   if (cw < 2 * kLanes) {
     if (lane == 0) atomicOr(status, 1);
     return;
   }
-  uint64_t x = (uint64_t)p[2 * lane] | ((uint64_t)p[2 * lane + 1] << 32);
+  uint32_t x = (uint32_t)p[2 * lane] | ((uint32_t)p[2 * lane + 1] << 16);
   int64_t ptr = 2 * kLanes;
   const int64_t base = c * kLanes * T;
 
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   // another lane (ds_bpermute), and the load that refills B is requested when the read position crosses into it: at
   // least 64 words, several steps, before its first word is needed.  (With ONE window reloaded at every new read
   // position, each step waited for a load it had just issued: the step time was the memory latency.)
-  auto window = [&](int64_t at) -> uint32_t { return at + lane < (int64_t)cw ? p[at + lane] : 0u; };
+  auto window = [&](int64_t at) -> uint32_t { return at + lane < (int64_t)cw ? (uint32_t)p[at + lane] : 0u; };
   int64_t wb = ptr & ~(int64_t)63;
   uint32_t win_a = window(wb), win_b = window(wb + 64);
   auto refill = [&](bool need) {
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
         bad |= 1;
         if (need) x = kL;   // keep the arithmetic defined; the status word reports the stream
       } else {
-        if (need) x = (x << 32) | w;
+        if (need) x = (x << 16) | w;
         ptr += cnt;
       }
       if (ptr - wb >= 64) {   // wave-uniform
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
       const uint32_t c0 = s_cdf[off + lo], c1 = s_cdf[off + lo + 1];
       uint32_t freq = (c1 - c0) & 0xFFFFu;
       if (freq == 0) freq = 65536;
-      x = (uint64_t)freq * (x >> 16) + cum - c0;
+      x = freq * (x >> 16) + cum - c0;
       value = lo;
       esc = lo == max_value;
     }
@@ -521,15 +524,15 @@ int pcc_rans_encode_dev_async(pcc_ctx* ctx, const pcc_rans_dev* tables, const in
   const int64_t T = steps_for(n), nc = chunks_for(n, T);
   PccProfScope prof(ctx, "rans_encode_dev", n, n_streams, T, nc);
   const int64_t cap_words = 2 * kLanes + (attempt == 0 ? kLanes * T * 3 / 2 + 64 : kLanes * T * 11);
-  const size_t work_bytes = (size_t)n_streams * nc * cap_words * 4;
+  const size_t work_bytes = (size_t)n_streams * nc * cap_words * 2;   // 16-bit words
   PCC_TRY(pcc_arena_reserve(ctx, work_bytes + pcc_align((size_t)n_streams * nc * 4) + 1024));
-  uint32_t* work = (uint32_t*)pcc_arena_alloc(ctx, work_bytes);
+  uint16_t* work = (uint16_t*)pcc_arena_alloc(ctx, work_bytes);
   uint32_t* words = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n_streams * nc * 4);
   if (!work || !words) return PCC_E_NOMEM;
   hipLaunchKernelGGL(k_rans_enc, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
                      view_of(tables), d_sym, d_idx, idx_run, n, T, nc, work, cap_words, words);
   PCC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_rans_pack, dim3((unsigned)(nc + 1), n_streams), dim3(256), 0, st, (const uint32_t*)work, cap_words,
+  hipLaunchKernelGGL(k_rans_pack, dim3((unsigned)(nc + 1), n_streams), dim3(256), 0, st, (const uint16_t*)work, cap_words,
                      (const uint32_t*)words, n, T, nc, d_out, cap_each, d_lens);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
@@ -573,15 +576,15 @@ extern "C" int pcc_rans_stream_info(const uint8_t* h_in, int64_t len, int64_t* h
               PCC_E_STREAM, "interleaved rANS stream: %lld symbols in %lld chunks of 64 x %lld", (long long)n, (long long)nc,
               (long long)T);
   PCC_REQUIRE(len >= 4 * (kHeaderWords + nc), PCC_E_STREAM, "interleaved rANS stream: truncated chunk table");
-  int64_t total = kHeaderWords + nc;
+  int64_t total = 4 * (kHeaderWords + nc);   // bytes: u32 header and chunk table, then 16-bit payload words
   for (int64_t c = 0; c < nc; ++c) {
     uint32_t cw;
     memcpy(&cw, h_in + 4 * (kHeaderWords + c), 4);
     PCC_REQUIRE(cw >= 2 * kLanes, PCC_E_STREAM, "interleaved rANS stream: chunk %lld has no states", (long long)c);
-    total += cw;
+    total += 2 * (int64_t)cw;
   }
-  PCC_REQUIRE(total * 4 == len, PCC_E_STREAM, "interleaved rANS stream: chunks take %lld bytes, stream has %lld",
-              (long long)(total * 4), (long long)len);
+  PCC_REQUIRE(total == len, PCC_E_STREAM, "interleaved rANS stream: chunks take %lld bytes, stream has %lld",
+              (long long)total, (long long)len);
   if (h_n) *h_n = n;
   if (h_steps) *h_steps = T;
   if (h_chunks) *h_chunks = nc;

@@ -419,19 +419,22 @@ ORC_API int orc_rans_decode(const uint8_t* in, int64_t len, const int32_t* idx, 
 /* -------------------------------------------------------------- interleaved rANS (container version 1) */
 
 /* [BUILD] The wave-interleaved stream of the product's GPU coder (csrc/rans_gpu.hip), restated sequentially.  The
- * coding step is the one above (CompressAI's: state 64 bit, L = 2^31, 32-bit words, 16-bit CDFs, escape bin followed
- * by the nibble count and the nibbles as bypass symbols); the symbols of an array are dealt to 64 states per chunk:
- *   stream  = u32 'PCI1' | u32 n | u32 T | u32 n_chunks | u32 words[n_chunks] | chunk payloads
+ * coding step is the rANS step above on the same 16-bit CDFs (escape bin followed by the nibble count and the nibbles as
+ * bypass symbols) with a state of 32 bits: L = 2^16, 16-bit renormalisation words (x_max = freq << 16; 2^28 for a bypass
+ * nibble) — half the final-state bytes per lane and chunk of the 64-bit form rounds 1-2 used.  The symbols of an array are
+ * dealt to 64 states per chunk:
+ *   stream  = u32 'PCI2' | u32 n | u32 T | u32 n_chunks | u32 words[n_chunks] | chunk payloads in 16-bit words
  *   chunk c = symbols [c 64 T, (c+1) 64 T); step t of lane l codes symbol c 64 T + 64 t + l
  *   payload = 64 x (state lo, state hi) | block(step 0, round 0) | block(0, 1) | .. | block(1, 0) | ..
  * Round 0 of a step codes the bins of all lanes, round r >= 1 the r-th bypass symbol of the lanes whose symbol
  * escaped (1 = nibble count, 2 + j = nibble j); a block holds the words the decoder reads after that round, in
- * ascending lane order.  T = 512 for arrays of more than 262144 symbols, 128 for more than 32768, else ceil(n / 64)
+ * ascending lane order.  T = 320 for arrays of more than 262144 symbols, 80 for more than 32768, else ceil(n / 64)
  * (one chunk), at least 1.
  * idx == NULL: table of symbol i = i / idx_run. */
 #define IL_LANES 64
-#define IL_MAGIC 0x31494350u
-static int64_t il_steps(int64_t n) { int64_t t = (n + IL_LANES - 1) / IL_LANES; if (n > 262144) return 512; if (n > 32768) return 128; return t < 1 ? 1 : t; }
+#define IL_MAGIC 0x32494350u   /* "PCI2": 32-bit states, 16-bit renormalisation words */
+#define IL_L (1u << 16)
+static int64_t il_steps(int64_t n) { int64_t t = (n + IL_LANES - 1) / IL_LANES; if (n > 262144) return 320; if (n > 32768) return 80; return t < 1 ? 1 : t; }
 
 typedef struct { uint32_t start, freq, raw; int nb, esc, act; } il_sym;
 
@@ -456,16 +459,17 @@ ORC_API int64_t orc_rans_interleaved_encode(const int32_t* sym, const uint8_t* i
   const int64_t T = il_steps(n);
   int64_t nc = (n + IL_LANES * T - 1) / (IL_LANES * T); if (nc < 1) nc = 1;
   const int64_t cw_cap = 2 * IL_LANES + IL_LANES * T * 11;
-  uint32_t* buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cw_cap);
+  uint16_t* buf = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cw_cap);
   uint32_t* o32 = (uint32_t*)out;
   if (cap < 4 * (4 + nc)) { free(buf); return -1; }
-  int64_t pos = 4 + nc;   /* words written */
+  uint16_t* o16 = (uint16_t*)(o32 + 4 + nc);
+  int64_t pos = 0;   /* 16-bit payload words written */
   o32[0] = IL_MAGIC; o32[1] = (uint32_t)n; o32[2] = (uint32_t)T; o32[3] = (uint32_t)nc;
   for (int64_t c = 0; c < nc; ++c) {
-    uint64_t x[IL_LANES];
+    uint32_t x[IL_LANES];
     il_sym sy[IL_LANES];
     int64_t ptr = cw_cap;
-    for (int l = 0; l < IL_LANES; ++l) x[l] = RANS_L;
+    for (int l = 0; l < IL_LANES; ++l) x[l] = IL_L;
     for (int64_t t = T - 1; t >= 0; --t) {
       for (int l = 0; l < IL_LANES; ++l) {
         const int64_t i = c * IL_LANES * T + t * IL_LANES + l;
@@ -477,12 +481,12 @@ ORC_API int64_t orc_rans_interleaved_encode(const int32_t* sym, const uint8_t* i
         int cnt = 0, need[IL_LANES];
         for (int l = 0; l < IL_LANES; ++l) {
           const int in = r == 0 ? sy[l].act : (sy[l].esc && r <= 1 + sy[l].nb);
-          const uint64_t x_max = r == 0 ? ((RANS_L >> 16) << 32) * (uint64_t)sy[l].freq : ((RANS_L >> 16) << 32) * 4096ull;
-          need[l] = in && x[l] >= x_max;
+          const uint64_t x_max = r == 0 ? ((uint64_t)sy[l].freq << 16) : ((uint64_t)4096 << 16);   /* ((L >> 16) << 16) * freq */
+          need[l] = in && (uint64_t)x[l] >= x_max;
           cnt += need[l];
         }
         ptr -= cnt;
-        for (int l = 0, k = 0; l < IL_LANES; ++l) if (need[l]) { buf[ptr + k++] = (uint32_t)x[l]; x[l] >>= 32; }
+        for (int l = 0, k = 0; l < IL_LANES; ++l) if (need[l]) { buf[ptr + k++] = (uint16_t)x[l]; x[l] >>= 16; }
         for (int l = 0; l < IL_LANES; ++l) {
           if (r == 0) { if (sy[l].act) x[l] = ((x[l] / sy[l].freq) << 16) + (x[l] % sy[l].freq) + sy[l].start; }
           else if (sy[l].esc && r <= 1 + sy[l].nb) {
@@ -493,15 +497,15 @@ ORC_API int64_t orc_rans_interleaved_encode(const int32_t* sym, const uint8_t* i
       }
     }
     ptr -= 2 * IL_LANES;
-    for (int l = 0; l < IL_LANES; ++l) { buf[ptr + 2 * l] = (uint32_t)x[l]; buf[ptr + 2 * l + 1] = (uint32_t)(x[l] >> 32); }
+    for (int l = 0; l < IL_LANES; ++l) { buf[ptr + 2 * l] = (uint16_t)x[l]; buf[ptr + 2 * l + 1] = (uint16_t)(x[l] >> 16); }
     const int64_t cw = cw_cap - ptr;
-    if ((pos + cw) * 4 > cap) { free(buf); return -1; }
+    if (4 * (4 + nc) + (pos + cw) * 2 > cap) { free(buf); return -1; }
     o32[4 + c] = (uint32_t)cw;
-    memcpy(o32 + pos, buf + ptr, (size_t)cw * 4);
+    memcpy(o16 + pos, buf + ptr, (size_t)cw * 2);
     pos += cw;
   }
   free(buf);
-  return pos * 4;
+  return 4 * (4 + nc) + pos * 2;
 }
 
 /* 0, or a negative code for a malformed stream */
@@ -512,13 +516,14 @@ ORC_API int orc_rans_interleaved_decode(const uint8_t* in, int64_t len, const ui
   if (len < 16 || w[0] != IL_MAGIC || (int64_t)w[1] != n) return -1;
   const int64_t T = w[2], nc = w[3];
   if (T < 1 || nc < 1 || len < 4 * (4 + nc) || IL_LANES * T * nc < n) return -1;
-  int64_t pos = 4 + nc;
+  const uint16_t* w16 = (const uint16_t*)(w + 4 + nc);
+  int64_t pos = 0;   /* 16-bit payload words consumed */
   for (int64_t c = 0; c < nc; ++c) {
     const int64_t cw = w[4 + c];
-    if (cw < 2 * IL_LANES || (pos + cw) * 4 > len) return -2;
-    const uint32_t* p = w + pos;
-    uint64_t x[IL_LANES];
-    for (int l = 0; l < IL_LANES; ++l) x[l] = (uint64_t)p[2 * l] | ((uint64_t)p[2 * l + 1] << 32);
+    if (cw < 2 * IL_LANES || 4 * (4 + nc) + (pos + cw) * 2 > len) return -2;
+    const uint16_t* p = w16 + pos;
+    uint32_t x[IL_LANES];
+    for (int l = 0; l < IL_LANES; ++l) x[l] = (uint32_t)p[2 * l] | ((uint32_t)p[2 * l + 1] << 16);
     int64_t ptr = 2 * IL_LANES;
     for (int64_t t = 0; t < T; ++t) {
       int in_r[IL_LANES], esc[IL_LANES], remaining[IL_LANES], jn[IL_LANES];
@@ -535,19 +540,19 @@ ORC_API int orc_rans_interleaved_decode(const uint8_t* in, int64_t len, const ui
         const uint32_t cum = (uint32_t)(x[l] & 0xFFFFu);
         int32_t s = 0;
         while (s + 1 < sizes[ci] - 1 && (uint32_t)cdf[s + 1] <= cum) ++s;
-        x[l] = (uint64_t)(uint32_t)(cdf[s + 1] - cdf[s]) * (x[l] >> 16) + cum - (uint32_t)cdf[s];
+        x[l] = (uint32_t)(cdf[s + 1] - cdf[s]) * (x[l] >> 16) + cum - (uint32_t)cdf[s];
         value[l] = s;
         esc[l] = s == maxv[l];
         any |= esc[l];
       }
-      for (int l = 0; l < IL_LANES; ++l) if (in_r[l] && x[l] < RANS_L) { if (ptr >= cw) return -2; x[l] = (x[l] << 32) | p[ptr++]; }
+      for (int l = 0; l < IL_LANES; ++l) if (in_r[l] && x[l] < IL_L) { if (ptr >= cw) return -2; x[l] = (x[l] << 16) | p[ptr++]; }
       if (any) {
         int active[IL_LANES], left = 0;
         for (int l = 0; l < IL_LANES; ++l) { active[l] = esc[l]; left += esc[l]; }
         while (left) {
           uint32_t val[IL_LANES];
           for (int l = 0; l < IL_LANES; ++l) if (active[l]) { val[l] = (uint32_t)(x[l] & 15u); x[l] >>= 4; }
-          for (int l = 0; l < IL_LANES; ++l) if (active[l] && x[l] < RANS_L) { if (ptr >= cw) return -2; x[l] = (x[l] << 32) | p[ptr++]; }
+          for (int l = 0; l < IL_LANES; ++l) if (active[l] && x[l] < IL_L) { if (ptr >= cw) return -2; x[l] = (x[l] << 16) | p[ptr++]; }
           for (int l = 0; l < IL_LANES; ++l) if (active[l]) {
             if (remaining[l] < 0) { if (val[l] > 8) return -3; remaining[l] = (int)val[l]; }
             else { raw[l] |= val[l] << (4 * jn[l]); ++jn[l]; --remaining[l]; }
@@ -566,7 +571,7 @@ ORC_API int orc_rans_interleaved_decode(const uint8_t* in, int64_t len, const ui
     }
     pos += cw;
   }
-  return pos * 4 == len ? 0 : -2;
+  return 4 * (4 + nc) + pos * 2 == len ? 0 : -2;
 }
 
 /* -------------------------------------------------------------- octree */

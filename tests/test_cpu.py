@@ -627,23 +627,26 @@ def _orc_interleaved(oracle, sym, idx, idx_run, cdf, sizes, offs):
 
 
 def test_interleaved_rans_known_answer_and_round_trip(oracle):
-    """the stream of container version 1 (csrc/rans_gpu.hip, restated in pcc_oracle.c), by hand for one symbol.
-    Table cdf = [0, 32768, 65536] (one regular bin, one escape bin), one symbol 0: one chunk of 64 x 1 steps, lane 0
-    codes the symbol, lanes 1..63 own nothing.  Lane 0: x = ((2^31 / 32768) << 16) + 0 = 2^32 (test_rans_known_answer),
-    no renormalisation word; the other states stay at L = 2^31.
-      header  'PCI1' | n = 1 | T = 1 | chunks = 1 | words[0] = 128 (the 64 states, two words each)
-      payload lane 0: (lo, hi) = (0, 1); lanes 1..63: (0x80000000, 0)"""
+    """the stream of container version 1 (csrc/rans_gpu.hip, restated in pcc_oracle.c: 32-bit states, L = 2^16, 16-bit
+    renormalisation words), by hand for one symbol.  Table cdf = [0, 32768, 65536] (one regular bin, one escape bin), one
+    symbol 0: one chunk of 64 x 1 steps, lane 0 codes the symbol, lanes 1..63 own nothing.  Lane 0: x = 2^16 < x_max =
+    freq << 16 = 2^31, no renormalisation word; x' = ((2^16 / 32768) << 16) + 2^16 % 32768 + 0 = 2^17; the other states
+    stay at L = 2^16.
+      header  'PCI2' | n = 1 | T = 1 | chunks = 1 | words[0] = 128 (the 64 states, two 16-bit words each)
+      payload lane 0: (lo, hi) = (0, 2); lanes 1..63: (0, 1)"""
     cdf = np.array([[0, 32768, 65536, 0]], dtype=np.int32)
     sizes, offs = np.array([3], np.int32), np.array([0], np.int32)
     got = _orc_interleaved(oracle, np.array([0], np.int32), np.zeros(1, np.uint8), 1, cdf, sizes, offs)
-    want = b"PCI1" + struct.pack("<IIII", 1, 1, 1, 128) + struct.pack("<II", 0, 1) + struct.pack("<II", 0x80000000, 0) * 63
+    want = b"PCI2" + struct.pack("<IIII", 1, 1, 1, 128) + struct.pack("<HH", 0, 2) + struct.pack("<HH", 0, 1) * 63
     assert got == want
-    # an escaped symbol in lane 1 adds bypass rounds but, from these states, still no word: sym = -3 -> the single-
-    # stream KAT's state 2^40 + 32849 (test_rans_bypass_escape_known_answers) appears as lane 1's final state
+    # an escaped symbol in lane 1 (sym = -3: raw = 5, one nibble; escape bin start 32768, freq 32768) adds bypass rounds,
+    # walked backwards by the encoder, and from these states still no word: nibble 5: x = (2^16 << 4) | 5 = 2^20 + 5;
+    # nibble count 1: x = (x << 4) | 1 = 2^24 + 81; bin: x = ((x / 32768) << 16) + x % 32768 + 32768 = (512 << 16) + 81 +
+    # 32768 = 2^25 + 32849: (lo, hi) = (32849, 512)
     got2 = _orc_interleaved(oracle, np.array([0, -3], np.int32), np.zeros(2, np.uint8), 1, cdf, sizes, offs)
-    lanes = struct.unpack_from("<128I", got2, 20)
-    assert struct.unpack_from("<IIII", got2, 4) == (2, 1, 1, 128) and len(got2) == 20 + 512
-    assert (lanes[0], lanes[1]) == (0, 1) and (lanes[2], lanes[3]) == (32849, 256)
+    lanes = struct.unpack_from("<128H", got2, 20)
+    assert struct.unpack_from("<IIII", got2, 4) == (2, 1, 1, 128) and len(got2) == 20 + 256
+    assert (lanes[0], lanes[1]) == (0, 2) and (lanes[2], lanes[3]) == (32849, 512)
     # round trips on the model's tables, table per symbol and table per channel run
     rng = np.random.default_rng(4)
     for which, n, run in (("gaussian_conditional", 70001, None), ("entropy_bottleneck", 32 * 500, 500)):
@@ -654,4 +657,4 @@ def test_interleaved_rans_known_answer_and_round_trip(oracle):
         data = oracle.rans_interleaved_encode(sym, idx, which, idx_run=run or 1)
         assert np.array_equal(oracle.rans_interleaved_decode(data, idx, n, which, idx_run=run or 1), sym)
         with pytest.raises(ValueError):
-            oracle.rans_interleaved_decode(data[:-4], idx, n, which, idx_run=run or 1)
+            oracle.rans_interleaved_decode(data[:-2], idx, n, which, idx_run=run or 1)

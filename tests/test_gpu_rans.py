@@ -51,8 +51,8 @@ def test_bytes_equal_oracle_and_round_trip(rt, oracle, coders, n):
     got = gc.encode(rt, rt.to_device(sym.reshape(1, -1)), rt.to_device(idx.reshape(1, -1)))[0]
     assert got == want
     magic, hn, steps, chunks = struct.unpack_from("<4sIII", got, 0)
-    assert magic == b"PCI1" and hn == n
-    assert steps == (512 if n > 262144 else 128 if n > 32768 else max((n + 63) // 64, 1))
+    assert magic == b"PCI2" and hn == n
+    assert steps == (320 if n > 262144 else 80 if n > 32768 else max((n + 63) // 64, 1))
     assert chunks == max(-(-n // (64 * steps)), 1)
     assert np.array_equal(oracle.rans_interleaved_decode(got, idx, n, "gaussian_conditional"), sym)
     back = gc.decode(rt, got, n, rt.to_device(idx) if n else None, 1)
@@ -88,7 +88,7 @@ def test_escape_heavy_input_takes_the_large_buffer(rt, oracle, coders):
 
 
 def test_rate_is_close_to_the_single_stream(rt, oracle, coders):
-    """the 64 states of a chunk cost 512 B; on a 1M-point-frame-sized array that is a few percent"""
+    """the 64 states of a chunk cost 256 B (chunks of 64 x 256 symbols); on a 1M-point-frame-sized array that is a few percent"""
     rng = np.random.default_rng(5)
     n = 32 * 26386
     sym, idx = _gaussian_case(oracle, rng, n)
