@@ -13,7 +13,10 @@ pass() {
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE
 pass b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS
 pass c SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL
-# (a pass with TA_* / TCP_* counters hung rocprofv3 on this pool: not collected)
+# TA_* / TCP_* counters are not collected: in round 2 one rocprofv3 pass with a TA_* / TCP_* set never returned on this pool
+# (gpurun killed it at its limit) and nothing of that run was kept — no log, no output directory — so neither the counter
+# nor the party at fault (profiler or driver; the kernel itself completes under every other pass) is known.  The exclusion
+# stays pinned to those two counter blocks; the SQ_VMEM_TA_*_FIFO_FULL counters of pass c cover the address path.
 cd $R
-python3 tools/pmc_sq.py $OUT "${2:-w4<true, true>}" > gpurun_out/${1:-pmc}_pmc_sq_conv.json
+python3 tools/pmc_sq.py $OUT "${2:-k_gconv_up}" > gpurun_out/${1:-pmc}_pmc_sq_conv.json
 cat gpurun_out/${1:-pmc}_pmc_sq_conv.json
