@@ -156,6 +156,10 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
     *reinterpret_cast<float4*>(base + HP) = make_float4(hi[0], hi[1], hi[2], hi[3]);
   };
+  // the records of the pipelined items are resolved for the reading lane once per step, in one group (input offset | qoff,
+  // accumulator address ^ q16): tile_read / tile_write take the resolved address
+  auto tile_read = [&](int addr, f32x4& lo, f32x4& hi) { acc_read(addr ^ q16, lo, hi); };
+  auto tile_write = [&](int addr, const f32x4& lo, const f32x4& hi) { acc_write(addr ^ q16, lo, hi); };
 
   // ---- remainder, first requests (their latency hides behind the sibling product): the two rows of lane l are
   // children `oct` of parents par0 + (l >> 3) and par0 + 8 + (l >> 3)
@@ -289,18 +293,41 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     }
   };
 #ifdef PCCUP_ABL_NEAR   // timing ablation: every gather from 16 KB of L1-resident rows
-  auto gather = [&](int g) { load_row(((uint32_t)rin[g] & 0x3F80u) | qoff, G[g][0], G[g][1]); };
+  auto gather = [&](int g) { load_row((uint32_t)rin[g] & 0x3FE0u, G[g][0], G[g][1]); };
 #else
-  auto gather = [&](int g) { load_row((uint32_t)rin[g] | qoff, G[g][0], G[g][1]); };
+  auto gather = [&](int g) { load_row((uint32_t)rin[g], G[g][0], G[g][1]); };
 #endif
+  auto resolve = [&](int (&racc)[NI]) {
+#pragma unroll
+    for (int g = 0; g < NI; ++g) {
+      rin[g] = (int)((uint32_t)rin[g] | qoff);
+      racc[g] ^= q16;
+      // materialised here: sunk to its use behind a conditional item, the value would be waited for with lgkmcnt(0) at the
+      // join — behind every LDS operation of the items in between
+      asm volatile("" : "+v"(rin[g]), "+v"(racc[g]));
+    }
+    asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(cb));   // requested with the records, arrived with them
+  };
 #ifdef PCCUP_ABL_NO123   // timing ablations: items 1 .. 3 never / all four items always
 #define PCCUP_LIVE(g) (cnt_cur > 16 * (g) + 1000000)
 #elif defined(PCCUP_ABL_ALL4)
 #define PCCUP_LIVE(g) true
+#elif defined(PCCUP_MINLIVE)   // items below PCCUP_MINLIVE run whether or not the offset has rows for them (pad slots: exact)
+#define PCCUP_LIVE(g) ((g) < PCCUP_MINLIVE || cnt_cur > 16 * (g))
 #else
 #define PCCUP_LIVE(g) (cnt_cur > 16 * (g))
 #endif
   int cnt_cur;
+#ifdef PCCUP_FILL_LOC   // timing ablation: eight independent register-only MFMAs at ONE place of the step — is there a stall to hide them in?
+  f32x4 fill_l = {0.f, 0.f, 0.f, 0.f}, fill_h = {1.f, 0.f, 0.f, 0.f};
+#define PCCUP_FILL_AT(loc) do { if constexpr ((loc) == PCCUP_FILL_LOC) { __builtin_amdgcn_sched_barrier(0); \
+      _Pragma("unroll") for (int f = 0; f < 8; ++f) { \
+        if (f & 1) fill_h = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[f & 7], wl[(f + 3) & 7], fill_h, 0, 0, 0); \
+        else fill_l = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[f & 7], wh[(f + 3) & 7], fill_l, 0, 0, 0); } \
+      __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define PCCUP_FILL_AT(loc) do { } while (0)
+#endif
   auto step = [&](int j, float4 (&Wc)[4], float4 (&Wn)[4], int (&rc_)[NI], int (&rn)[NI]) {
 #if PCC_CONV_STAMP
     unsigned long long tq[8];
@@ -333,33 +360,58 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       }
     }
     PCCUP_T(6);
-    // item 0 is unconditional (pad slots into the sink row when the offset has no row) and carries the bookkeeping of
-    // the step between its MFMAs: one basic block (conv16.h)
-    acc_read(rc_[0], lo0, hi0);
-    acc_read(rc_[1], lo1, hi1);
-    float xv0[8];
-    shape(G[0][0], G[0][1], xv0);
-    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv0[0], lo0, 0, 0, 0);
-    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv0[0], hi0, 0, 0, 0);
+    // item 0 is unconditional (pad slots into the sink row when the offset has no row).  The step's bookkeeping sits in
+    // front of its MFMAs as ONE group of vector instructions, behind the request for the tiles (their LDS round trip runs
+    // under it): a vector instruction between two MFMAs costs a lone wave 16 cycles, in a group 4 (tools/micro/issue.hip),
+    // and f32 MFMAs share the vector ALU — whatever the partner wave does, this time is not hidden.  The records arrive
+    // under the first four MFMA pairs; they are resolved and the first gather of the next offset issued in the middle.
+    PCCUP_FILL_AT(1);
+    tile_read(rc_[0], lo0, hi0);
+    tile_read(rc_[1], lo1, hi1);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef PCCUP_SUB_COMPACT   // timing subtractions (wrong results): pieces of the bookkeeping left out
+    const int cnt_next = cnt_cur;
+#else
     const int cnt_next = compact();   // offset j + 1
-    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[1], xv0[1], lo0, 0, 0, 0);
-    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[1], xv0[1], hi0, 0, 0, 0);
-    request_nb();         // book entries of offset j + 2
+#endif
+#ifndef PCCUP_SUB_REQ
+    request_nb();                     // book entries of offset j + 2
     request_lut(j + 3);
-    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[2], xv0[2], lo0, 0, 0, 0);
-    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[2], xv0[2], hi0, 0, 0, 0);
+#endif
+#ifdef PCCUP_SUB_W
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Wn[i] = Wc[i];
+#else
     load_wj(Wn, j + 1);
-    lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[3], xv0[3], lo0, 0, 0, 0);
-    hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[3], xv0[3], hi0, 0, 0, 0);
+#endif
+#ifdef PCCUP_SUB_COMPACT
+#pragma unroll
+    for (int g = 0; g < NI; ++g) rn[g] = rc_[g];
+#else
     PCC16_SYNC();
     read_records(rn);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    PCCUP_FILL_AT(2);
+    float xv0[8];
+    shape(G[0][0], G[0][1], xv0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv0[s], lo0, 0, 0, 0);
+      hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef PCCUP_SUB_COMPACT
+    resolve(rn);
+#endif
+    gather(0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 4; s < 8; ++s) {
       lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv0[s], lo0, 0, 0, 0);
       hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
     }
-    if (!PCCUP_LIVE(1)) acc_write(rc_[0], lo0, hi0);
-    gather(0);
+    if (!PCCUP_LIVE(1)) tile_write(rc_[0], lo0, hi0);
     PCCUP_T(5);   // item 0 with the bookkeeping
     // Item g >= 1: [write-back of item g-1 behind the first MFMA pair, tile of item g+1 requested] chains of item g; the
     // last item of the step writes itself back.  The gathers of the next offset's four items are issued whether or not
@@ -368,19 +420,20 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
 #define PCCUP_ITEM(g, LO, HI, PLO, PHI)                                                                \
     if (PCCUP_LIVE(g)) {                                                                               \
       const bool more = (g) + 1 < NI && PCCUP_LIVE((g) + 1);                                           \
+      PCCUP_FILL_AT(3);                                                                                \
       float xv[8];                                                                                     \
       shape(G[g][0], G[g][1], xv);                                                                     \
       LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
       HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[0], xv[0], HI, 0, 0, 0);                            \
-      acc_write(rc_[(g) - 1], PLO, PHI);                                                               \
-      if constexpr ((g) + 1 < NI) acc_read(rc_[(g) + 1 < NI ? (g) + 1 : 0], PLO, PHI);                 \
+      tile_write(rc_[(g) - 1], PLO, PHI);                                                              \
+      if constexpr ((g) + 1 < NI) { if (more) tile_read(rc_[(g) + 1 < NI ? (g) + 1 : 0], PLO, PHI); } \
       _Pragma("unroll") for (int s = 1; s < 8; ++s) {                                                  \
         LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], LO, 0, 0, 0);                          \
         HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], HI, 0, 0, 0);                          \
       }                                                                                                \
-      if (!more) acc_write(rc_[g], LO, HI);                                                            \
+      if (!more) { PCCUP_FILL_AT(4); tile_write(rc_[g], LO, HI); }                                     \
     }                                                                                                  \
-    gather(g)
+    gather(g); PCCUP_FILL_AT(5)
     PCCUP_ITEM(1, lo1, hi1, lo0, hi0);
     PCCUP_ITEM(2, lo0, hi0, lo1, hi1);
     PCCUP_ITEM(3, lo1, hi1, lo0, hi0);
@@ -412,6 +465,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   load_wj(W0, 0);
   PCC16_SYNC();
   read_records(ra0);
+  resolve(ra0);
 #pragma unroll
   for (int g = 0; g < NI; ++g) gather(g);
 #ifndef PCCUP_NO_IRR
@@ -421,6 +475,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   }
 #endif
   PCC16_SYNC();
+#ifdef PCCUP_FILL_LOC
+  if (in_bytes == 12345u) acc_lds[lane] = fill_l[0] + fill_h[0];
+#endif
 
 #ifdef PCCUP_NO_EPI   // timing ablation: one word per lane instead of the epilogue
   head_out[row0 + lane] = acc_lds[acc_at(0, lane, q)];
