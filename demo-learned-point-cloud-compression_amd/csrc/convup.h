@@ -183,7 +183,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     nb0 = pr[0];
     nb1 = pr[8];
   };
-  // pack the rows that have the requested offset (under another parent) into the slot records; returns their count
+  // pack the rows that have the requested offset (under another parent) into the slot records; returns their count.
+  // (Pad records written to every lane's own two slots first, then the present rows' records over them under EXEC: 10
+  // vector instructions instead of 22, two more LDS writes and two EXEC regions — 0.6 % slower.)
   auto compact = [&]() -> int {
     const bool p0 = nb0 >= 0, p1 = nb1 >= 0;
     const unsigned long long bal0 = __builtin_amdgcn_ballot_w64(p0), bal1 = __builtin_amdgcn_ballot_w64(p1);
@@ -483,19 +485,40 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   head_out[row0 + lane] = acc_lds[acc_at(0, lane, q)];
   return;
 #endif
-  // ---- epilogue: the window's rows are contiguous in `out` (nullptr with the colour head: the last stage of g_s)
-  if (out != nullptr)
+  // ---- epilogue: the window's rows are contiguous in `out` (nullptr with the colour head: the last stage of g_s).  Vector
+  // instructions are what the epilogue costs (they share the ALU with the partner wave's MFMAs): one v_max per element
+  // (no canonicalising copy in front of it), LDS and store addresses as immediates off one register, rows past the end
+  // dropped by the store's buffer bounds instead of a compare per row
+  auto relu1 = [&](float v) -> float {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));   // +0 for -0, 0 for a quiet NaN: v > 0 ? v : 0
+    return r;
+  };
+  if (out != nullptr) {
+    const int64_t rows_left = n_out - row0;
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        out + row0 * 32, 0, (int)((rows_left < R ? rows_left : R) * 128), 0x00027000);
+    // row it * 8 + grow, piece chunk: the swizzle of acc_at does not depend on `it` (8 rows = 2 swizzle periods)
+    const float* lp = &acc_lds[acc_at(chunk >> 2, grow, chunk & 3)];
+    const uint32_t voff = (uint32_t)grow * 128u + (uint32_t)chunk * 16u;
+    auto store_rows = [&](auto with_relu) {   // one straight-line body per case: the reads of all rows in flight together
+      float4 v[R / 8];
 #pragma unroll
-    for (int it = 0; it < R / 8; ++it) {
-      const int r = it * 8 + grow;
-      float4 v = *reinterpret_cast<const float4*>(&acc_lds[acc_at(chunk >> 2, r, chunk & 3)]);
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      for (int it = 0; it < R / 8; ++it) v[it] = *reinterpret_cast<const float4*>(lp + it * 8 * 16);
+#pragma unroll
+      for (int it = 0; it < R / 8; ++it) {
+        float4 t = v[it];
+        if constexpr (decltype(with_relu)::value) { t.x = relu1(t.x); t.y = relu1(t.y); t.z = relu1(t.z); t.w = relu1(t.w); }
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t d = {__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(d, out_rs, voff, it * 1024, 0);
       }
-      if (row0 + r < n_out) *reinterpret_cast<float4*>(out + (row0 + r) * 32 + chunk * 4) = v;
-    }
+    };
+    if (relu) store_rows(std::true_type{}); else store_rows(std::false_type{});
+  }
   // occupancy head (32 -> 1) and, at the last stage, the colour head (32 -> 3, no activation) of the lane's two rows:
   // c ascending fmaf chains, the bits of pcc_linear on the stored rows
+  auto heads = [&](auto with_relu) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int r = lane + 64 * h;
@@ -510,7 +533,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v = vv[j];
-        if (relu) v = fmaxf(v, 0.f);
+        if constexpr (decltype(with_relu)::value) v = relu1(v);
         hv = fmaf(v, head_w[4 * c4 + j], hv);
         if (rgb_out != nullptr) {
 #pragma unroll
@@ -527,6 +550,8 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       }
     }
   }
+  };
+  if (relu) heads(std::true_type{}); else heads(std::false_type{});
 #if PCC_CONV_STAMP
   {   // shader clock over the wave's life: s_memtime ticks per 100-MHz s_memrealtime tick, x 1000 (st_sum[1] = kHz / 100)
     unsigned long long rt1, mt1;
