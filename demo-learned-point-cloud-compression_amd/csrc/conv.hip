@@ -349,6 +349,159 @@ __global__ __launch_bounds__(64) void k_convT16(
   }
 }
 
+// k_convT16 as persistent waves: a wave keeps the weights of all 8 octants in registers (128) for its whole life and
+// walks tiles of 16 parents, the next tile's rows (and the row index of the one after, when the rows are gathered)
+// requested before the current tile's first store.  Nothing the chains wait for is ever younger than a store: in
+// k_convT16 the weights of octant o + 2 were requested behind the stores of octant o, and vmcnt retires in order — every
+// wave waited for its stores to be acknowledged once per octant.  Weight traffic from L2: 32 KB per wave instead of per
+// 16 parents (835 MB -> 64 MB for the 408k-parent stage).
+#ifndef PCC_CT16P_WPS
+#define PCC_CT16P_WPS 2   // waves per SIMD
+#endif
+template <bool ROWS, bool RELU>
+__global__ __launch_bounds__(64, PCC_CT16P_WPS) void k_convT16p(
+    const float* __restrict__ in, int64_t n_in, const float* __restrict__ wsw, const float* __restrict__ bias,
+    float* __restrict__ out, const uint32_t* __restrict__ rows, int64_t n_tiles) {
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(uint32_t)(n_in * 1024), 0x00027000);
+  __shared__ __attribute__((aligned(16))) float tile[2][2][16 * 16];
+  const int lane = threadIdx.x, n = lane & 15, q = lane >> 4, grow = lane >> 3, chunk = lane & 7;
+  float4 W[8][4];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const float4* wp = reinterpret_cast<const float4*>(wsw + (int64_t)o * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[o][j] = wp[j];
+  }
+  const float* bp = bias + 4 * q;
+  // the weights have arrived HERE: left to the loop, their wait (vmcnt retires in order) would stand in front of every
+  // tile's chains and cover the previous tile's stores
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(W[o][j].x), "+v"(W[o][j].y), "+v"(W[o][j].z), "+v"(W[o][j].w));
+  const int64_t last = n_in - 1;
+  auto parent_of = [&](int64_t t) -> int64_t {   // clamped: a slot past the end reloads the last row, its stores are dropped
+    const int64_t p = t * 16 + n;
+    return p < n_in ? p : last;
+  };
+  auto row_index = [&](int64_t t) -> int64_t {   // a tile past the wave's last: the last tile again (loaded, never used)
+    const int64_t p = parent_of(t < n_tiles ? t : n_tiles - 1);
+    if constexpr (ROWS) return (int64_t)rows[p];
+    return p;
+  };
+  auto load_rows = [&](int64_t src, float4& g0, float4& g1) {
+    const float4* xp = reinterpret_cast<const float4*>(in + src * 32 + q * 8);
+    g0 = xp[0];
+    g1 = xp[1];
+  };
+  const int64_t stride = gridDim.x;
+  int64_t t = blockIdx.x;
+  if (t >= n_tiles) return;
+  float4 g0, g1;
+  load_rows(row_index(t), g0, g1);
+  int64_t src_next = row_index(t + stride);
+  // nothing pending on entry (the loop header joins this state with the back edge's: a load still in flight here would be
+  // waited for at the top of every tile, behind the previous tile's stores)
+  asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w), "+v"(src_next));
+  float bias8[8] = {bp[0], bp[1], bp[2], bp[3], bp[16], bp[17], bp[18], bp[19]};
+  asm volatile("" : "+v"(bias8[0]), "+v"(bias8[1]), "+v"(bias8[2]), "+v"(bias8[3]), "+v"(bias8[4]), "+v"(bias8[5]), "+v"(bias8[6]), "+v"(bias8[7]));
+  const f32x4 bl = {bias8[0], bias8[1], bias8[2], bias8[3]}, bh = {bias8[4], bias8[5], bias8[6], bias8[7]};
+  for (; t < n_tiles; t += stride) {
+    float xv[8];
+    {
+      unsigned m[2][4] = {{__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)},
+                          {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)}};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        u32x2 w2 = __builtin_amdgcn_permlane32_swap(m[b][0], m[b][2], false, false);
+        m[b][0] = w2[0]; m[b][2] = w2[1];
+        w2 = __builtin_amdgcn_permlane32_swap(m[b][1], m[b][3], false, false);
+        m[b][1] = w2[0]; m[b][3] = w2[1];
+        w2 = __builtin_amdgcn_permlane16_swap(m[b][0], m[b][1], false, false);
+        m[b][0] = w2[0]; m[b][1] = w2[1];
+        w2 = __builtin_amdgcn_permlane16_swap(m[b][2], m[b][3], false, false);
+        m[b][2] = w2[0]; m[b][3] = w2[1];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) xv[2 * t4 + b] = __uint_as_float(m[b][t4]);
+      }
+    }
+    // next tile's rows and the index of the one after: in flight before this tile's first store
+    load_rows(src_next, g0, g1);
+    src_next = row_index(t + 2 * stride);
+    const int64_t p0 = t * 16;
+    // the rows of octant o leave (LDS read + stores) behind the chains of octant o + 1: the turn through LDS has a whole
+    // chain to complete in
+    auto store_octant = [&](int o) {
+      float (&T)[2][16 * 16] = tile[o & 1];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r = grow + 8 * it;
+        const float4 v = *reinterpret_cast<const float4*>(&T[chunk >> 2][r * 16 + 4 * (chunk & 3)]);
+        const uint32_t off = (uint32_t)(((p0 + r) * 8 + o) * 128 + 16 * chunk);   // beyond the buffer for a parent past the end
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, out_rs, off, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const float wl[8] = {W[o][0].x, W[o][0].y, W[o][0].z, W[o][0].w, W[o][1].x, W[o][1].y, W[o][1].z, W[o][1].w};
+      const float wh[8] = {W[o][2].x, W[o][2].y, W[o][2].z, W[o][2].w, W[o][3].x, W[o][3].y, W[o][3].z, W[o][3].w};
+      f32x4 lo = bl, hi = bh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        lo = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (o > 0) store_octant(o - 1);
+      float4 a = make_float4(lo[0], lo[1], lo[2], lo[3]), b = make_float4(hi[0], hi[1], hi[2], hi[3]);
+      if constexpr (RELU) {
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+        b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+      }
+      float (&T)[2][16 * 16] = tile[o & 1];
+      *reinterpret_cast<float4*>(&T[0][n * 16 + 4 * q]) = a;
+      *reinterpret_cast<float4*>(&T[1][n * 16 + 4 * q]) = b;
+      PCC16_SYNC();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_octant(7);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+static int convT16_waves() {   // two waves per SIMD on every CU of the device
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = cus * 4 * PCC_CT16P_WPS;
+  }
+  return n;
+}
+
+static void launch_convT16(hipStream_t st, const float* d_in, int64_t n_in, const float* wsw, const float* d_bias, int relu,
+                           float* d_out, const uint32_t* d_rows) {
+  const int64_t n_tiles = (n_in + 15) / 16;
+  static const bool one_shot = getenv("PCC_CONVT_ONESHOT") != nullptr;   // A/B switch: the one-tile-per-wave form
+  // from 4 tiles per resident wave on (a wave with 4 tiles beside one with 3 leaves a quarter of the machine idle at the
+  // end: 106k parents = 3.2 tiles per wave take 36.6 us this way, 33.1 us one tile per wave; 408k: 97 against 135)
+  if (one_shot || n_tiles < 4 * (int64_t)convT16_waves()) {
+    hipLaunchKernelGGL(k_convT16, dim3((unsigned)n_tiles), dim3(64), 0, st, d_in, n_in, wsw, d_bias, relu, d_out, d_rows);
+  } else {
+    const dim3 grid((unsigned)convT16_waves());
+    if (d_rows) {
+      if (relu) hipLaunchKernelGGL((k_convT16p<true, true>), grid, dim3(64), 0, st, d_in, n_in, wsw, d_bias, d_out, d_rows, n_tiles);
+      else hipLaunchKernelGGL((k_convT16p<true, false>), grid, dim3(64), 0, st, d_in, n_in, wsw, d_bias, d_out, d_rows, n_tiles);
+    } else {
+      if (relu) hipLaunchKernelGGL((k_convT16p<false, true>), grid, dim3(64), 0, st, d_in, n_in, wsw, d_bias, d_out, d_rows, n_tiles);
+      else hipLaunchKernelGGL((k_convT16p<false, false>), grid, dim3(64), 0, st, d_in, n_in, wsw, d_bias, d_out, d_rows, n_tiles);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_convT_scalar(
     const float* __restrict__ in, int64_t n_in, const float* __restrict__ w,
     const float* __restrict__ bias, int cin, int cout, int relu, float* __restrict__ out) {
@@ -811,8 +964,7 @@ extern "C" int pcc_convT_gen(pcc_ctx* ctx, const float* d_in, int64_t n_in, cons
       !convT_legacy()) {
     const float* wsw;
     PCC_TRY(weights_for(ctx, d_w, 8, 32, &wsw));
-    hipLaunchKernelGGL(k_convT16, dim3(nblk(n_in, 16)), dim3(64), 0, st, d_in, n_in, wsw, d_bias, relu, d_out,
-                       (const uint32_t*)nullptr);
+    launch_convT16(st, d_in, n_in, wsw, d_bias, relu, d_out, nullptr);
   } else if (!force_scalar() && aligned && convT_widths(cin, cout)) {
     launch_convT_any(st, d_in, n_in, d_w, d_bias, relu, d_out, nullptr, cin, cout);
   } else {
@@ -852,7 +1004,7 @@ extern "C" int pcc_convT_gen_gather(pcc_ctx* ctx, const float* d_in, const uint3
   if ((uintptr_t)d_out % 16 == 0 && n_in < ((int64_t)1 << 22) && !convT_legacy()) {
     const float* wsw;
     PCC_TRY(weights_for(ctx, d_w, 8, 32, &wsw));
-    hipLaunchKernelGGL(k_convT16, dim3(nblk(n_in, 16)), dim3(64), 0, ctx->stream, d_in, n_in, wsw, d_bias, relu, d_out, d_rows);
+    launch_convT16(ctx->stream, d_in, n_in, wsw, d_bias, relu, d_out, d_rows);
   } else {
     launch_convT<32>(ctx->stream, d_in, n_in, d_w, d_bias, relu, d_out, d_rows, 32);
   }

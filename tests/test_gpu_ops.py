@@ -665,6 +665,21 @@ def test_convT_on_gathered_rows(rt, oracle):
     assert np.array_equal(host(out), oracle.convT(x[rows], w, b, True))
 
 
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("n", [131072, 140001, 170017])
+def test_convT_persistent_waves_bit_exact(rt, oracle, n, relu):
+    """from 4 tiles per resident wave on, the 32 -> 32 up stage runs as persistent waves (k_convT16p: weights in registers,
+    tiles walked with a stride of the grid): whole tiles, a ragged last tile, waves with 4, 5 and 6 tiles; plain and gathered"""
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=(n + 1000, 32)).astype(np.float32)
+    w, b = _weights(rng, 8, 32, 32)
+    out = rt.convT_gen(dev(rt, x[:n]), dev(rt, w), dev(rt, b), relu)
+    assert np.array_equal(host(out), oracle.convT(x[:n], w, b, relu))
+    rows = np.sort(rng.choice(n + 1000, n, replace=False)).astype(np.int32)
+    out = rt.convT_gen_gather(dev(rt, x), dev(rt, rows), dev(rt, w), dev(rt, b), relu)
+    assert np.array_equal(host(out), oracle.convT(x[rows], w, b, relu))
+
+
 def test_linear_on_gathered_rows(rt, oracle):
     """the colour head on the kept rows in place (pcc_linear_gather) == gather then linear, == oracle"""
     rng = np.random.default_rng(9)
