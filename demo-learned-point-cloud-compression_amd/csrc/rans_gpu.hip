@@ -173,6 +173,11 @@ static RansView view_of(const pcc_rans_dev* t) { return RansView{t->d_cdf, t->d_
 // ---- encoder -----------------------------------------------------------------------------------------------------
 // One wave per chunk.  work: per stream and chunk a private buffer of cap_words; the chunk ends at the buffer's end.
 // words_out[s * n_chunks + c] = words of the chunk (0xFFFFFFFF: the buffer was too small).
+// Every global load and store of the coding loop is UNCONDITIONAL (clamped index / an offset beyond the buffer for a
+// lane that has nothing to write): vmcnt retires in order, and with one conditional access in the loop the compiler
+// can only wait with vmcnt(0) — for the symbol it had requested a moment ago and for every 2-byte store before it, so a
+// step lasted one memory latency whatever the depth of the queue.
+template <bool HAS_IDX>
 __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __restrict__ sym,
                                                   const uint8_t* __restrict__ idx, int64_t idx_run, int64_t n,
                                                   int64_t T, int64_t n_chunks, uint16_t* __restrict__ work,
@@ -194,15 +199,35 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
   const int64_t base = c * kLanes * T;
 
   // symbol and table index of the step after this one are requested before this step's arithmetic
+  // the stream's table indexes as dwords from the aligned address below their first byte (pointer arithmetic only: a
+  // pointer made from an integer is a FLAT pointer, and flat loads count on both wait counters)
+  const int64_t sidx_mis = HAS_IDX ? (int64_t)((uintptr_t)sidx & 3) : 0;
+  const uint32_t* sidx32 = HAS_IDX ? reinterpret_cast<const uint32_t*>(sidx - sidx_mis) : nullptr;
   auto fetch = [&](int64_t t, int32_t& sv, int& rv) {
     const int64_t i = base + t * kLanes + lane;
-    sv = 0;
-    rv = 0;
-    if (t >= 0 && i < n) {
-      sv = ssym[i];
-      rv = sidx ? (int)sidx[i] : (int)(i / idx_run);
-      rv = rv < tv.n_cdf ? rv : tv.n_cdf - 1;   // a table index out of range never reaches the LDS tables (the entry points check what they can)
-    }
+    const bool live = t >= 0 && i < n;
+    const int64_t ic = live ? i : 0;   // n >= 1 (the entry point does not launch for an empty stream)
+    // raw: nothing here may consume a loaded value (the consumer, prep, runs kEncAhead - 1 steps later) — the table
+    // index comes as the aligned dword that holds its byte (a byte load is followed at once by its zero-extension)
+    sv = ssym[ic];
+    if constexpr (HAS_IDX) rv = (int)sidx32[(ic + sidx_mis) >> 2];
+    else rv = (int)(ic / idx_run);
+  };
+  // the chunk's word buffer as a buffer resource: a lane without a word stores beyond it (dropped, no traffic)
+  // (the chunk is the wave's: its address is the same in every lane, said to the compiler with readfirstlane — a
+  // descriptor it cannot prove uniform is applied lane by lane in a loop)
+  const uint64_t buf_u = (uint64_t)buf;
+  uint16_t* buf_w = reinterpret_cast<uint16_t*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(buf_u >> 32)) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)buf_u));
+  const __amdgpu_buffer_rsrc_t buf_rs = __builtin_amdgcn_make_buffer_rsrc(buf_w, 0, (int)(uint32_t)(cap_words * 2), 0x00027000);
+  auto emit = [&](bool need) {   // the low halves of the states that renormalise, packed downwards from ptr
+    const unsigned long long bal = __ballot(need);
+    const int cnt = __popcll(bal);
+    const bool room = ptr - cnt >= 2 * kLanes;
+    overflow |= !room;
+    ptr -= room ? cnt : 0;
+    const uint32_t off = (need && room) ? (uint32_t)(ptr + lane_rank(bal)) * 2u : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x, buf_rs, off, 0, 0);
   };
   // kEncAhead steps of symbols and table indexes are in flight: a step's own arithmetic is a few hundred cycles, a
   // load that misses L2 takes longer than that, and with one step of distance the step time WAS the memory latency.
@@ -225,6 +250,8 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
     const int64_t i = base + t * kLanes + lane;
     p.act = t >= 0 && i < n;
     if (p.act) {
+      if constexpr (HAS_IDX) r = (int)(((uint32_t)r >> (8 * (int)((i + sidx_mis) & 3))) & 0xFFu);
+      r = r < tv.n_cdf ? r : tv.n_cdf - 1;   // a table index out of range never reaches the LDS tables (the entry points check what they can)
       const int off = s_row[3 * r], len = s_row[3 * r + 1];
       const int32_t max_value = len - 2;
       int32_t v = sv - s_row[3 * r + 2];
@@ -265,15 +292,7 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
         const bool in = esc && r <= 1 + nb;
         if (__ballot(in) == 0ull) continue;
         const bool need = in && x >= (1u << 28);   // ((L >> 16) << 16) * 2^12
-        const unsigned long long bal = __ballot(need);
-        const int cnt = __popcll(bal);
-        if (cnt) {
-          if (ptr - cnt < 2 * kLanes) overflow = true;
-          else {
-            ptr -= cnt;
-            if (need) buf[ptr + lane_rank(bal)] = (uint16_t)x;
-          }
-        }
+        emit(need);
         if (need) x >>= 16;
         if (in) {
           const uint32_t val = r == 1 ? (uint32_t)nb : (raw >> (4 * (r - 2))) & 15u;
@@ -283,15 +302,7 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
     }
     {  // round 0: the symbol's bin
       const bool need = act && (uint64_t)x >= ((uint64_t)(uint32_t)freq << 16);   // ((L >> 16) << 16) * freq (freq may be 2^16)
-      const unsigned long long bal = __ballot(need);
-      const int cnt = __popcll(bal);
-      if (cnt) {
-        if (ptr - cnt < 2 * kLanes) overflow = true;
-        else {
-          ptr -= cnt;
-          if (need) buf[ptr + lane_rank(bal)] = (uint16_t)x;
-        }
-      }
+      emit(need);
       if (need) x >>= 16;
       if (act) {
         // x / freq, x % freq with x < 2^16 freq: the quotient from one multiplication by 1 / freq in double (exact operands,
@@ -368,7 +379,12 @@ __global__ __launch_bounds__(256) void k_rans_pack(const uint16_t* __restrict__ 
 }
 
 // ---- decoder -----------------------------------------------------------------------------------------------------
-// status (int32): OR of 1 = a chunk ran out of words, 2 = malformed escape
+// status (int32): OR of 1 = a chunk ran out of words, 2 = malformed escape, 4 = a table index out of range.
+// As in the encoder every global access of the coding loop is unconditional (a clamped index, a buffer whose bounds
+// drop what must not be written, a window load whose result is only adopted where it is needed), so that the waits
+// keep the depth of the queues: with one conditional access in the loop every wait was vmcnt(0).
+// The stream buffer must be readable up to the next multiple of 4 bytes (its words are fetched as aligned dwords).
+template <bool HAS_IDX>
 __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* __restrict__ in /* the stream */,
                                                   const uint8_t* __restrict__ idx, int64_t idx_run, int64_t n,
                                                   int64_t T, int64_t n_chunks, int32_t* __restrict__ sym,
@@ -396,47 +412,64 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
   int64_t ptr = 2 * kLanes;
   const int64_t base = c * kLanes * T;
 
+  // The chunk's words behind a buffer descriptor over its aligned dwords: word j is half (j + mis) & 1 of dword
+  // (j + mis) >> 1, a dword past the chunk's end reads as 0.  (Wave-uniform values are said to be so with readfirstlane.)
+  auto uniform_ptr = [](const void* q) -> uint64_t {
+    const uint64_t u = (uint64_t)q;
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  };
+  const uint64_t p_u = uniform_ptr(p);
+  const int mis = (int)((p_u >> 1) & 1);
+  const uint32_t cw_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw);
+  const uint32_t cw_u = cw_r < 0x3FFFFFF0u ? cw_r : 0x3FFFFFF0u;   // the descriptor's byte count is 32 bits (a count this large is refused below: out of words)
+  const __amdgpu_buffer_rsrc_t win_rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(p_u & ~(uint64_t)3), 0, (int)((((cw_u + (uint32_t)mis) * 2u) + 3u) & ~3u), 0x00027000);
   // The words of the chunk are held 128 at a time in two registers per lane — A = words [wb, wb + 64), B = the 64 behind
   // them, wb a multiple of 64 with wb <= ptr < wb + 64 — so a lane that renormalises takes its word from a register of
-  // another lane (ds_bpermute), and the load that refills B is requested when the read position crosses into it: at
-  // least 64 words, several steps, before its first word is needed.  (With ONE window reloaded at every new read
-  // position, each step waited for a load it had just issued: the step time was the memory latency.)
-  auto window = [&](int64_t at) -> uint32_t { return at + lane < (int64_t)cw ? (uint32_t)p[at + lane] : 0u; };
+  // another lane (ds_bpermute).  Lane l of a window at `at` holds the DWORD with word at + l (the half is picked after
+  // the shuffle).
+  auto window = [&](int64_t at) -> uint32_t {
+    return __builtin_amdgcn_raw_buffer_load_b32(win_rs, (uint32_t)(((at + lane + mis) >> 1) << 2), 0, 0);
+  };
   int64_t wb = ptr & ~(int64_t)63;
   uint32_t win_a = window(wb), win_b = window(wb + 64);
   auto refill = [&](bool need) {
     const unsigned long long bal = __ballot(need);
     const int cnt = __popcll(bal);
-    if (cnt) {
-      const int at = (int)(ptr - wb) + lane_rank(bal);   // 0 .. 126
-      const uint32_t wa = (uint32_t)__shfl((int)win_a, at & 63, 64), wbv = (uint32_t)__shfl((int)win_b, at & 63, 64);
-      const uint32_t w = at < 64 ? wa : wbv;
-      if (ptr + cnt > (int64_t)cw) {
-        bad |= 1;
-        if (need) x = kL;   // keep the arithmetic defined; the status word reports the stream
-      } else {
-        if (need) x = (x << 16) | w;
-        ptr += cnt;
-      }
-      if (ptr - wb >= 64) {   // wave-uniform
-        wb += 64;
-        win_a = win_b;
-        win_b = window(wb + 64);
-      }
-    }
+    const int at = (int)(ptr - wb) + lane_rank(bal);   // 0 .. 126
+    const uint32_t wa = (uint32_t)__shfl((int)win_a, at & 63, 64), wbv = (uint32_t)__shfl((int)win_b, at & 63, 64);
+    const uint32_t dw = at < 64 ? wa : wbv;
+    const uint32_t w = (dw >> (16 * ((at + mis) & 1))) & 0xFFFFu;   // wb is even: the parity of word wb + at is that of at
+    const bool fits = ptr + cnt <= (int64_t)cw;
+    if (!fits && cnt) bad |= 1;
+    if (need) x = fits ? (x << 16) | w : kL;   // out of words: keep the arithmetic defined; the status word reports the stream
+    ptr += fits ? cnt : 0;
+    const bool cross = ptr - wb >= 64;   // wave-uniform
+    wb += cross ? 64 : 0;
+    win_a = cross ? win_b : win_a;   // B is stale after a crossing until request_b()
   };
-  // table indexes: kDecAhead steps in flight
+  // B for the next refill: requested once per step at a place every path of the step runs through, crossing or not (the
+  // same window again when not: the same words) and always adopted — no branch and no select on a value in flight, and
+  // the state of the wait counter is the same on every path into the next step.  It is first read one step from here.
+  auto request_b = [&]() { win_b = window(wb + 64); };
+  // table indexes: kDecAhead steps in flight, as the aligned dword that holds the byte (extracted where it is used)
   constexpr int kDecAhead = 8;
+  const int64_t idx_mis = HAS_IDX ? (int64_t)((uintptr_t)idx & 3) : 0;
+  const uint32_t* idx32 = HAS_IDX ? reinterpret_cast<const uint32_t*>(idx - idx_mis) : nullptr;
   auto fetch_idx = [&](int64_t t) -> int {
     const int64_t i = base + t * kLanes + lane;
-    if (t >= T || i >= n) return 0;
-    const int r = idx ? (int)idx[i] : (int)(i / idx_run);
-    if (r >= tv.n_cdf) bad |= 4;   // reported through the status word; the tables are read at the last row instead
-    return r < tv.n_cdf ? r : tv.n_cdf - 1;
+    const int64_t ic = (t < T && i < n) ? i : 0;
+    if constexpr (HAS_IDX) return (int)idx32[(ic + idx_mis) >> 2];
+    return (int)(ic / idx_run);
   };
   int r_q[kDecAhead];
 #pragma unroll
   for (int d = 0; d < kDecAhead; ++d) r_q[d] = fetch_idx(d);
+  // the chunk's symbols behind a descriptor: a lane past the end of the stream stores beyond it (dropped)
+  const int64_t chunk_syms = n - base < kLanes * T ? n - base : kLanes * T;
+  const __amdgpu_buffer_rsrc_t sym_rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(uniform_ptr(sym + base)), 0,
+      __builtin_amdgcn_readfirstlane((int)(uint32_t)((chunk_syms > 0 ? chunk_syms : 0) * 4)), 0x00027000);
 
   for (int64_t t0 = 0; t0 < T; t0 += kDecAhead) {
 #pragma unroll
@@ -445,11 +478,16 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
     if (t >= T) break;   // wave-uniform
     const int64_t i = base + t * kLanes + lane;
     const bool act = i < n;
-    const int r = r_q[d];
+    int r = r_q[d];
     r_q[d] = fetch_idx(t + kDecAhead);
     int32_t value = 0, max_value = 0, off_sym = 0;
     bool esc = false;
     if (act) {
+      if constexpr (HAS_IDX) r = (int)(((uint32_t)r >> (8 * (int)((i + idx_mis) & 3))) & 0xFFu);
+      if (r >= tv.n_cdf) {   // reported through the status word; the tables are read at the last row instead
+        bad |= 4;
+        r = tv.n_cdf - 1;
+      }
       const int off = s_row[3 * r], len = s_row[3 * r + 1];
       off_sym = s_row[3 * r + 2];
       max_value = len - 2;
@@ -471,6 +509,7 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
     refill(act && x < kL);
     if (__ballot(esc) != 0ull) {
       // bypass rounds: round 1 reads the nibble count, the following rounds the nibbles, least significant first
+      request_b();   // (the rare path requests and waits on its own)
       bool in = esc;
       int remaining = -1, j = 0;
       uint32_t raw = 0;
@@ -481,6 +520,7 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
           x >>= 4;
         }
         refill(in && x < kL);
+        request_b();
         if (in) {
           if (remaining < 0) {
             if (val > 8) bad |= 2;   // a 32-bit value has at most 8 nibbles
@@ -499,7 +539,8 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
         else value += max_value;
       }
     }
-    if (act) sym[i] = value + off_sym;
+    request_b();
+    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(value + off_sym), sym_rs, (uint32_t)((t * kLanes + lane) * 4), 0, 0);
    }
   }
   const unsigned long long b1 = __ballot((bad & 1) != 0), b2 = __ballot((bad & 2) != 0), b4 = __ballot((bad & 4) != 0);
@@ -529,8 +570,15 @@ int pcc_rans_encode_dev_async(pcc_ctx* ctx, const pcc_rans_dev* tables, const in
   uint16_t* work = (uint16_t*)pcc_arena_alloc(ctx, work_bytes);
   uint32_t* words = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n_streams * nc * 4);
   if (!work || !words) return PCC_E_NOMEM;
-  hipLaunchKernelGGL(k_rans_enc, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
-                     view_of(tables), d_sym, d_idx, idx_run, n, T, nc, work, cap_words, words);
+  // an empty stream still runs one chunk (its final states): its (masked) loads read the scratch instead of a null array
+  const int32_t* sym_arg = n ? d_sym : (const int32_t*)words;
+  const int64_t run_arg = idx_run >= 1 ? idx_run : 1;
+  if (d_idx && n)
+    hipLaunchKernelGGL(k_rans_enc<true>, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
+                       view_of(tables), sym_arg, d_idx, run_arg, n, T, nc, work, cap_words, words);
+  else
+    hipLaunchKernelGGL(k_rans_enc<false>, dim3(nblk(nc, kChunksPerWg), n_streams), dim3(256), tables->lds_bytes(), st,
+                       view_of(tables), sym_arg, (const uint8_t*)nullptr, run_arg, n, T, nc, work, cap_words, words);
   PCC_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_rans_pack, dim3((unsigned)(nc + 1), n_streams), dim3(256), 0, st, (const uint16_t*)work, cap_words,
                      (const uint32_t*)words, n, T, nc, d_out, cap_each, d_lens);
@@ -599,8 +647,14 @@ extern "C" int pcc_rans_decode_dev(pcc_ctx* ctx, const pcc_rans_dev* tables, con
               PCC_E_ARG, "pcc_rans_decode_dev: bad argument");
   PCC_REQUIRE((uintptr_t)d_in % 4 == 0, PCC_E_ARG, "pcc_rans_decode_dev: stream must be 4-byte aligned");
   PccProfScope prof(ctx, "rans_decode_dev", n, 1, steps, n_chunks);
-  hipLaunchKernelGGL(k_rans_dec, dim3(nblk(n_chunks, kChunksPerWg)), dim3(256), tables->lds_bytes(), ctx->stream,
-                     view_of(tables), (const uint32_t*)d_in, d_idx, idx_run, n, steps, n_chunks, d_sym, d_status);
+  const int64_t run_arg = idx_run >= 1 ? idx_run : 1;
+  if (d_idx && n)
+    hipLaunchKernelGGL(k_rans_dec<true>, dim3(nblk(n_chunks, kChunksPerWg)), dim3(256), tables->lds_bytes(), ctx->stream,
+                       view_of(tables), (const uint32_t*)d_in, d_idx, run_arg, n, steps, n_chunks, d_sym, d_status);
+  else
+    hipLaunchKernelGGL(k_rans_dec<false>, dim3(nblk(n_chunks, kChunksPerWg)), dim3(256), tables->lds_bytes(), ctx->stream,
+                       view_of(tables), (const uint32_t*)d_in, (const uint8_t*)nullptr, run_arg, n, steps, n_chunks, d_sym,
+                       d_status);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -441,7 +441,11 @@ int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx,
  * and ORs d_status (int32, device) with 1 / 2 / 4 if a chunk runs out of words /
  * an escape is malformed / a table index is not below n_cdf (the last row is
  * used instead) — test it after the next synchronisation.  encode clamps table
- * indexes the same way; with d_idx == NULL it refuses n > idx_run * n_cdf. */
+ * indexes the same way; with d_idx == NULL it refuses n > idx_run * n_cdf.
+ * The coding loops read d_idx and the stream as aligned 32-bit words: the
+ * device allocations behind d_in (decode) and d_idx (both) must be readable up
+ * to the next multiple of 4 bytes beyond their last byte (any hipMalloc'd or
+ * framework-allocated buffer is). */
 typedef struct pcc_rans_dev pcc_rans_dev;
 pcc_rans_dev* pcc_rans_dev_create(const int32_t* h_cdfs, int cdf_pitch,
                                   const int32_t* h_sizes, const int32_t* h_offsets,
