@@ -76,6 +76,16 @@ def main():
                     turn[0] = (turn[0] + 1) % 4
                     return rt.sparse_conv_head_up(xs[turn[0]], pn, w, b, True, hw, hb)
                 fns.append(("head_up_cold", cold))
+                # ... and behind the launch that precedes it in the decoder: the up stage writing these rows (its time is
+                # taken off with a run of the up stage alone)
+                par = torch.randn((pruned2.n, 32), generator=gw, device="cuda").contiguous()
+                w8 = (torch.randn((8, 32, 32), generator=gw, device="cuda") * 0.1).contiguous()
+                fns.append(("up alone", lambda: rt.convT_gen(par, w8, b, True)))
+
+                def chained():
+                    xin = rt.convT_gen(par, w8, b, True)
+                    return rt.sparse_conv_head_up(xin, pn, w, b, True, hw, hb)
+                fns.append(("up+head_up", chained))
             for label, fn in fns:
                 for _ in range(3):
                     fn()

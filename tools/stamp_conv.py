@@ -71,6 +71,14 @@ def main():
         for i, nm in enumerate(NAMES):
             print(f"  {nm:24s} {a[:, i].mean():10.0f}  {a[:, i].mean() / 27:8.0f} / step   {100 * a[:, i].mean() / tot:5.1f} %")
         print(f"  {'sum':24s} {tot:10.0f}  {tot / 27:8.0f} / step")
+        if os.environ.get("PCC_CONVUP"):
+            span = (a[:, 7].max() - a[:, 6].min()) * 0.01
+            life = (a[:, 7] - a[:, 6]) * 0.01
+            print("  sampled waves: first start to last end %.1f us; wave life mean %.1f us (p99 %.1f); resident waves (6 x sum of lives / span) %.0f"
+                  % (span, life.mean(), np.percentile(life, 99), 6 * life.sum() / span))
+            t2 = a[:, [0, 2, 3, 4, 5, 8]].sum(1)
+            print("  window totals (stamped phases, cycles): mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f; items per window mean %.1f p99 %.0f max %.0f"
+                  % (t2.mean(), *np.percentile(t2, [50, 90, 99]), t2.max(), a[:, 9].mean(), np.percentile(a[:, 9], 99), a[:, 9].max()))
     rt.close()
 
 
