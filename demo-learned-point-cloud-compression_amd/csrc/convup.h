@@ -342,13 +342,17 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
     const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
     // items beyond the pipeline (more than 64 rows of the window have the offset) first, while the list is still in
-    // LDS: record, rows, tile, chains, one by one (items of one offset touch disjoint rows: their order is free).  The
-    // branch ends with nothing of its own in flight, so the counts of the prefetches stay exact.
+    // LDS (items of one offset touch disjoint rows: their order is free).
     if (cnt_cur > 16 * NI) {
+      // the next item's record and rows are requested before this item's chains (a pad record behind the last item: its
+      // load returns zeros without a fetch) — one item at a time, each lasted a record read + a row fetch + a tile read
+      int2 r = rec[NI * 16 + n];
+      float4 g0, g1;
+      load_row((uint32_t)r.x | qoff, g0, g1);
       for (int g = NI; 16 * g < cnt_cur; ++g) {
-        const int2 r = rec[g * 16 + n];
-        float4 g0, g1;
-        load_row((uint32_t)r.x | qoff, g0, g1);
+        const int2 rn2 = rec[(g + 1 < R / 16 ? g + 1 : R / 16 - 1) * 16 + n];
+        float4 h0, h1;
+        load_row((uint32_t)rn2.x | qoff, h0, h1);
         f32x4 lo, hi;
         acc_read(r.y, lo, hi);
         float xv[8];
@@ -359,6 +363,9 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
           hi = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], hi, 0, 0, 0);
         }
         acc_write(r.y, lo, hi);
+        r = rn2;
+        g0 = h0;
+        g1 = h1;
       }
     }
     PCCUP_T(6);
