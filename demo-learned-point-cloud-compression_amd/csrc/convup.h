@@ -165,12 +165,16 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   // children `oct` of parents par0 + (l >> 3) and par0 + 8 + (l >> 3)
   const int oct = lane & 7;
   int32_t pbv[7];   // element e = lane + 64 i of the slice: offset e >> 4, parent e & 15
+  // (unconditional loads off a descriptor with 32-bit offsets — the book is below 27 x 2^24 entries —: an entry that does
+  // not exist is requested beyond the book and replaced by -1 where the slice is written to LDS)
+  const __amdgpu_buffer_rsrc_t book_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbrp), 0, (int)(uint32_t)(27 * pitch * 4), 0x00027000);
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int e = lane + 64 * i;
     const int64_t pp = par0 + (e & 15);
-    pbv[i] = -1;
-    if (e < 27 * 16 && (e >> 4) != 13 && pp < n_par) pbv[i] = nbrp[(int64_t)(e >> 4) * pitch + pp];
+    const bool have = e < 27 * 16 && (e >> 4) != 13 && pp < n_par;
+    pbv[i] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(book_rs, have ? (uint32_t)(((int64_t)(e >> 4) * pitch + pp) * 4) : 0xFFFFFFF0u, 0, 0);
   }
   int32_t nb0 = -1, nb1 = -1;   // rows of the parent-level neighbours of the lane's two parents (-1: none, or a sibling offset)
   uint32_t nb_op7 = 0u;         // octant of the neighbour inside that parent, << 7
@@ -270,8 +274,11 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     for (int o = 0; o < 8; ++o) acc_write(acc_row(8 * n + o), lo[o], hi[o]);
     if (lane < 8) *reinterpret_cast<float4*>(&acc_lds[acc_at(lane >> 2, R, lane & 3)]) = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
-      if (lane + 64 * i < 27 * 16) pb[lane + 64 * i] = pbv[i];
+    for (int i = 0; i < 7; ++i) {
+      const int e = lane + 64 * i;
+      const bool have = (e >> 4) != 13 && par0 + (e & 15) < n_par;
+      if (e < 27 * 16) pb[e] = have ? pbv[i] : -1;
+    }
     if (lane < 54) reinterpret_cast<uint32_t*>(lut)[lane] = reinterpret_cast<const uint32_t*>(kPccUpLut.b)[lane];
 #ifdef PCCUP_FAT_LDS
     if (in_bytes == 12345u) acc_lds[lane] = fat_lds[lane ^ 1];
