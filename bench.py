@@ -2,7 +2,8 @@
 """bench.py — frames/s of encode+decode on the ScanNet-scale 1M-point frame.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by the driver under torch.distributed.run, one rank per GPU)
+    (N > 1: either under torch.distributed.run — RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment — or
+     plain, in which case this process starts the N ranks itself: launch_ranks())
 
 One step = the reference's operator contract: CompressionPipeline.compress(gop of host numpy frames as the
 capturer leaves them — int16 points, float64 colours — at the three quality settings of shared/config.yaml:12-15)
@@ -92,6 +93,51 @@ def cpu_baseline(wl, frame, n_sample, threads, runs=5, warmups=2):
                        f"restatement with OpenMP on {threads} threads")}, full
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it (the driver's command): start the N ranks here, one
+    fresh child process per GPU, with the environment torch.distributed.run would give them.  This parent never
+    touches the GPU (torch.cuda.device_count() does not initialise it) and never execs: it relays the children's
+    output (rank 0 prints the JSON line), waits for all of them and returns the worst exit code.  A rank that fails
+    is not restarted; the others are then ended by their own PIDs, since they would wait for it in a barrier."""
+    import socket
+    import subprocess
+    backend = os.environ.get("PCC_BENCH_BACKEND", "nccl")
+    import torch
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs for one RCCL rank each, this node shows {have}; no line printed",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, failed_at = 0, None
+    live = dict(enumerate(procs))
+    while live:
+        for r, p in list(live.items()):
+            rc = p.poll()
+            if rc is None:
+                continue
+            del live[r]
+            if rc != 0:
+                log(f"bench.py: rank {r} ended with code {rc}")
+                worst = worst or rc
+                if failed_at is None:
+                    failed_at = time.time()
+                    for q in live.values():
+                        q.terminate()
+        if failed_at is not None and time.time() - failed_at > 20.0:
+            for q in live.values():
+                q.kill()
+        time.sleep(0.05)
+    return worst if worst > 0 else (1 if worst else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,11 +151,15 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="also report throughput with this many GOPs in flight (0/1 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # plain `python bench.py --gpus N`: this process only starts the ranks
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}: refusing to print a line for another world size")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # one rank per GPU; PCC_BENCH_BACKEND=gloo lets several ranks share a GPU (used only to rehearse
     # the multi-rank control flow on a one-GPU box — RCCL refuses two ranks on one device)
@@ -486,6 +536,8 @@ def main():
             "cpu_baseline": cpu,
             "throughput_in_flight": inflight,
         }
+        if line["ranks_seen"] != line["n_gpus"] or line["n_gpus"] != args.gpus:
+            sys.exit(f"bench.py: {line['ranks_seen']} ranks seen for --gpus {args.gpus}: no line printed")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
