@@ -71,6 +71,10 @@ PROTOTYPES = {
     "pcc_subset_map_up": (i32, [vp, vp, i64, vp, vp, i64, vp]),
     "pcc_octree_encode": (i32, [vp, vp, i64, i32, vp, i64, pi64]),
     "pcc_octree_decode": (i32, [vp, i64, vp, i64, pi64]),
+    "pcc_octree_encode_version": (i32, [vp, vp, i64, i32, i32, vp, i64, pi64]),
+    "pcc_octree_blob_version": (i32, [vp, i64]),
+    "pcc_octree_decode_ctx": (i32, [vp, vp, i64, vp, i64, pi64]),
+    "pcc_octree_decode_dev": (i32, [vp, vp, i64, vp, i64, pi64, pi64]),
     "pcc_abi_version": (i32, []),
     "pcc_last_error": (C.c_char_p, []),
     "pcc_create": (vp, [i32, vp]),

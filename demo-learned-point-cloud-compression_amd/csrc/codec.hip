@@ -269,6 +269,27 @@ struct pcc_codec {
   std::vector<int64_t> rec_offsets;
 };
 
+// ---------------------------------------------------------------- geometry slot (utils.py)
+void octree_root(uint64_t first, uint64_t last, int key_shift, int* depth, int32_t origin[3]) {
+  const uint64_t mask48 = ((uint64_t)1 << 48) - 1;
+  const uint64_t a = (first & mask48) >> key_shift, b = (last & mask48) >> key_shift;
+  const uint64_t diff = a ^ b;
+  int d = 1;
+  if (diff) d = (63 - __builtin_clzll(diff)) / 3 + 1;
+  const uint64_t corner = (a >> (3 * d)) << (3 * d);
+  const int bias = 32768 >> (key_shift / 3);
+  auto compact = [](uint64_t v) {
+    int r = 0;
+    for (int i = 0; i < 16; ++i) r |= (int)((v >> (3 * i)) & 1) << i;
+    return r;
+  };
+  *depth = d;
+  origin[0] = compact(corner >> 2) - bias;
+  origin[1] = compact(corner >> 1) - bias;
+  origin[2] = compact(corner) - bias;
+}
+
+
 namespace {
 
 #define CODEC_ALLOC(var, type, count)                                        \
@@ -591,26 +612,6 @@ int h_s_out_at(pcc_codec* cd, const Feat& pre, const CS* ycs, const View& yv, fl
   }
   *out = o;
   return PCC_OK;
-}
-
-// ---------------------------------------------------------------- geometry slot (utils.py)
-void octree_root(uint64_t first, uint64_t last, int key_shift, int* depth, int32_t origin[3]) {
-  const uint64_t mask48 = ((uint64_t)1 << 48) - 1;
-  const uint64_t a = (first & mask48) >> key_shift, b = (last & mask48) >> key_shift;
-  const uint64_t diff = a ^ b;
-  int d = 1;
-  if (diff) d = (63 - __builtin_clzll(diff)) / 3 + 1;
-  const uint64_t corner = (a >> (3 * d)) << (3 * d);
-  const int bias = 32768 >> (key_shift / 3);
-  auto compact = [](uint64_t v) {
-    int r = 0;
-    for (int i = 0; i < 16; ++i) r |= (int)((v >> (3 * i)) & 1) << i;
-    return r;
-  };
-  *depth = d;
-  origin[0] = compact(corner >> 2) - bias;
-  origin[1] = compact(corner >> 1) - bias;
-  origin[2] = compact(corner) - bias;
 }
 
 void put_be32(std::vector<uint8_t>& v, int32_t x) {
@@ -1173,6 +1174,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     int depth;
     int32_t origin[3];
     std::vector<int64_t> level_n;
+    std::vector<uint8_t> v2;   // a frame above PCC_OCTREE_V2_MIN_LEAVES leaves: its finished blob (octree2.hip)
   };
   std::vector<FrameGeo> geo((size_t)n_frames);
   double geo_dev_s = 0;
@@ -1241,6 +1243,14 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     for (int f = 0; f < n_frames; ++f) {
       FrameGeo& g = geo[f];
       if (g.n == 0) continue;
+      if (g.n > PCC_OCTREE_V2_MIN_LEAVES) {   // blob version 2: levels AND entropy coder on the GPU
+        const int64_t cap2 = 4096 + 17 * g.n;
+        int64_t len2 = 0;
+        g.v2.resize((size_t)cap2);
+        PCC_TRY(pcc_octree2_encode(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, g.origin, g.v2.data(), cap2, &len2));
+        g.v2.resize((size_t)len2);
+        continue;
+      }
       g.level_n.assign((size_t)g.depth, 0);
       PCC_TRY(pcc_octree_levels(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, occ + g.occ_off, g.n * g.depth,
                                 g.level_n.data()));
@@ -1316,7 +1326,11 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_TRY(geometry_arrived());
     const double t = now_s();
     for (int f = 0; f < n_frames; ++f) {
-      const FrameGeo& g = geo[f];
+      FrameGeo& g = geo[f];
+      if (!g.v2.empty()) {
+        blobs[f].swap(g.v2);
+        continue;
+      }
       const int64_t cap = 64 + 2 * g.occ_len + 16;
       blobs[f].resize((size_t)cap);
       int64_t len = 0;
@@ -1753,7 +1767,13 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   for (int f = 0; f < n_frames; ++f) {
     if (fn[f] == 0) continue;
     int64_t level_n[16];
-    PCC_TRY(pcc_octree_unpack_vec(slots[f].p, slots[f].len, &fpts[f], level_n));
+    if (slots[f].p[1] == 2) {   // blob version 2: decoded by the GPU; fn[f] has passed the plausibility checks above
+      int64_t n2 = 0;
+      fpts[f].resize((size_t)(3 * fn[f]));
+      PCC_TRY(pcc_octree2_decode(ctx, slots[f].p, slots[f].len, nullptr, fpts[f].data(), fn[f], &n2, level_n));
+    } else {
+      PCC_TRY(pcc_octree_unpack_vec(slots[f].p, slots[f].len, &fpts[f], level_n));
+    }
     PCC_REQUIRE((int64_t)fpts[f].size() == 3 * fn[f], PCC_E_STREAM, "pcc_decode_gop: frame %d decoded %zu points, announced %lld",
                 f, fpts[f].size() / 3, (long long)fn[f]);
     const int depth = fdepth[f];
@@ -2249,35 +2269,7 @@ extern "C" int pcc_decode_fetch(pcc_codec* cd, int32_t* d_coords, float* d_color
 }
 
 // ---------------------------------------------------------------------------- geometry slot, one call each
-extern "C" int pcc_octree_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, uint8_t* h_out,
-                                 int64_t cap, int64_t* h_len) {
-  PCC_REQUIRE(ctx && h_out && h_len && n >= 0 && (n == 0 || d_keys), PCC_E_ARG, "pcc_octree_encode: bad argument");
-  const int64_t zero = 0;
-  const int32_t org0[3] = {0, 0, 0};
-  if (n == 0) return pcc_octree_pack(nullptr, &zero, 0, 0, org0, h_out, cap, h_len);
-  uint64_t ends[2];
-  PCC_HIP(hipMemcpyAsync(&ends[0], d_keys, 8, hipMemcpyDeviceToHost, ctx->stream));
-  PCC_HIP(hipMemcpyAsync(&ends[1], d_keys + (n - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-  PCC_HIP(hipStreamSynchronize(ctx->stream));
-  int depth;
-  int32_t origin[3];
-  octree_root(ends[0], ends[1], key_shift, &depth, origin);
-  uint8_t* d_occ = nullptr;
-  PCC_HIP(hipMalloc((void**)&d_occ, (size_t)n * depth));
-  std::vector<int64_t> level_n((size_t)depth, 0);
-  int rc = pcc_octree_levels(ctx, d_keys, n, key_shift, depth, d_occ, n * depth, level_n.data());
-  std::vector<uint8_t> occ;
-  if (rc == PCC_OK) {
-    int64_t tot = 0;
-    for (int64_t v : level_n) tot += v;
-    occ.resize((size_t)std::max<int64_t>(tot, 1));
-    if (hipMemcpy(occ.data(), d_occ, (size_t)tot, hipMemcpyDeviceToHost) != hipSuccess) rc = PCC_E_HIP;
-  }
-  (void)hipFree(d_occ);
-  PCC_TRY(rc);
-  return pcc_octree_pack(occ.data(), level_n.data(), depth, n, origin, h_out, cap, h_len);
-}
-
+// (pcc_octree_encode and the forms that take a context: octree2.hip)
 extern "C" int pcc_octree_decode(const uint8_t* h_in, int64_t len, int32_t* h_points, int64_t cap_points,
                                  int64_t* h_n_points) {
   int64_t n = 0;

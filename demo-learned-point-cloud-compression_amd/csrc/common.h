@@ -57,6 +57,9 @@ struct pcc_ctx {
   struct pcc_prof_rec* prof;
   // weights in MFMA operand order, by device pointer (pcc_conv_prepare, conv.hip)
   struct PccWeightCache* wcache;
+  // pinned staging grown on demand (octree2.hip: blobs and decoded points on their way over PCIe)
+  void* stage;
+  size_t stage_cap;
 };
 
 struct pcc_prof_rec {

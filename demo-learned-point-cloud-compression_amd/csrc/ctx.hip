@@ -52,6 +52,7 @@ extern "C" void pcc_destroy(pcc_ctx* c) {
   pcc_wcache_free(c);
   if (c->arena) (void)hipFree(c->arena);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->stage) (void)hipHostFree(c->stage);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   for (int i = 0; i < c->prof_cap; ++i)

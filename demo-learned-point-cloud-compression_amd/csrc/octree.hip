@@ -3,50 +3,21 @@
 // Device half of the replacement for utils.gpcc_encode (shared/utils.py:169):
 // the reference hands the latent coordinates to the tmc3 subprocess through an
 // ASCII PLY file; here the coordinates never leave HBM until they are
-// occupancy bytes.  Leaves are Morton-sorted, so the children of a node are
-// adjacent: each level is an adjacent-unique pass (flag, prefix scan, emit)
-// and the occupancy byte of a node is the OR of (1 << octant) over <= 8
-// consecutive entries.  Node counts stay on the device until one read-back at
-// the end; the level arrays are then packed root-first into d_occ.
+// occupancy bytes.  All levels follow from the sorted leaves directly (see
+// k_oct_small): with h = the highest bit in which leaf e differs from leaf
+// e-1, e opens a new node at every level L >= lmin(e) = depth - h / 3, so
+//   nodes at level L          = #{e : lmin(e) <= L}
+//   node of leaf e at level L = #{e' <= e : lmin(e') <= L} - 1
+// and the leaf that opens a node at level L+1 sets bit (leaf >> 3 (depth-L-1)) & 7
+// in its level-L node.  Latent-sized inputs (<= 65536 leaves): one workgroup,
+// one launch.  Larger inputs (round 4; rounds 1-3 walked the levels bottom-up,
+// five launches per level): per-wave counts of lmin <= L, ONE scan over the
+// [level][wave] table, and one pass that ranks the leaves per level with
+// ballots and ORs the octants into the root-first packed array — six launches
+// whatever the depth.
 #include "common.h"
 
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
-
-__global__ void k_oct_flags(const uint64_t* __restrict__ cur, const uint32_t* __restrict__ n_cur_p,
-                            int64_t n_max, uint32_t* __restrict__ flags) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_max) return;
-  const int64_t n_cur = (int64_t)*n_cur_p;
-  uint32_t f = 0;
-  if (i < n_cur) f = (i == 0 || (cur[i - 1] >> 3) != (cur[i] >> 3)) ? 1u : 0u;
-  flags[i] = f;
-}
-
-__global__ void k_oct_emit(const uint64_t* __restrict__ cur, const uint32_t* __restrict__ n_cur_p,
-                           const uint32_t* __restrict__ flags, const uint32_t* __restrict__ excl,
-                           uint64_t* __restrict__ parents, uint8_t* __restrict__ occ) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n_cur = (int64_t)*n_cur_p;
-  if (i >= n_cur || !flags[i]) return;
-  const uint64_t pk = cur[i] >> 3;
-  uint32_t byte = 0;
-  for (int64_t j = i; j < n_cur && j < i + 8; ++j) {
-    const uint64_t k = cur[j];
-    if ((k >> 3) != pk) break;
-    byte |= 1u << (uint32_t)(k & 7ull);
-  }
-  const uint32_t p = excl[i];
-  parents[p] = pk;
-  occ[p] = (uint8_t)byte;
-}
-
-__global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
-
-__global__ void k_oct_leaves(const uint64_t* __restrict__ keys, int64_t n, int shift, uint64_t mask,
-                             uint64_t* __restrict__ leaves) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) leaves[i] = (keys[i] >> shift) & mask;
-}
 
 // ---- single-workgroup form (n <= OCT_SMALL_MAX): every level in one launch, from the leaves alone -----------
 // Latent frames are ~1e3..3e4 leaves; per-level launches are pure launch latency for them, and walking the
@@ -220,91 +191,170 @@ int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int 
   return PCC_OK;
 }
 
+// ---- many-workgroup form (n > OCT_SMALL_MAX): one wave per 64 consecutive leaves -----------------------------
+// hist[L][w] = leaves of wave w that open a level-L node (lmin <= L); rows L >= depth stay 0
+__global__ __launch_bounds__(256) void k_octw_hist(const uint64_t* __restrict__ keys, int64_t n, int shift, uint64_t mask,
+                                                   int depth, int64_t n_waves, uint32_t* __restrict__ hist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves) return;
+  const int64_t e = w * 64 + lane, ec = e < n ? e : n - 1;
+  const uint64_t kc = (keys[ec] >> shift) & mask, kp = ec > 0 ? (keys[ec - 1] >> shift) & mask : 0ull;
+  const int lm = e < n ? oct_lmin(kp, kc, e == 0, depth) : OCT_MAXD + 2;
+  uint32_t mine = 0;
+  for (int L = 0; L < depth; ++L) {
+    const uint32_t c = (uint32_t)__popcll(__ballot(lm <= L));
+    mine = lane == L ? c : mine;
+  }
+  if (lane < OCT_MAXD) hist[(int64_t)lane * n_waves + w] = mine;
+}
+
+// from the exclusive scan of hist (flattened [16][n_waves]): counts[L] = nodes of level L (counts[depth] = leaves),
+// offs[L] = bytes in front of level L in the root-first packed array (offs[depth] = all nodes)
+__global__ void k_octw_offsets(const uint32_t* __restrict__ scan, const uint32_t* __restrict__ total, int64_t n_waves,
+                               int depth, uint32_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ offs) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t off = 0;
+  for (int L = 0; L < depth; ++L) {
+    const uint32_t lo = scan[(int64_t)L * n_waves], hi = L + 1 < OCT_MAXD ? scan[(int64_t)(L + 1) * n_waves] : *total;
+    counts[L] = hi - lo;
+    offs[L] = off;
+    off += hi - lo;
+  }
+  counts[depth] = n;
+  offs[depth] = off;
+}
+
+__global__ __launch_bounds__(256) void k_octw_zero(uint32_t* __restrict__ occ32, const uint32_t* __restrict__ offs, int depth,
+                                                   int64_t cap_words) {
+  int64_t words = ((int64_t)offs[depth] + 3) / 4;
+  words = words < cap_words ? words : cap_words;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < words; j += (int64_t)gridDim.x * blockDim.x) occ32[j] = 0u;
+}
+
+// ranks the wave's leaves per level and ORs the octants in.  The bits of lanes that hit the same 32-bit word are
+// merged inside the wave first (the children of a node and the nodes of a word are neighbouring lanes: a segmented OR
+// over runs of equal word index), so that a word receives one atomic per wave that touches it
+__global__ __launch_bounds__(256) void k_octw_emit(const uint64_t* __restrict__ keys, int64_t n, int shift, uint64_t mask,
+                                                   int depth, int64_t n_waves, const uint32_t* __restrict__ scan,
+                                                   const uint32_t* __restrict__ offs, uint32_t* __restrict__ occ32,
+                                                   int64_t cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_waves) return;
+  if ((int64_t)offs[depth] > cap) return;   // the host sees the counts and reports the capacity error
+  const uint64_t lanes_le = ~0ull >> (63 - lane);
+  const int64_t e = w * 64 + lane, ec = e < n ? e : n - 1;
+  const bool valid = e < n;
+  const uint64_t kc = (keys[ec] >> shift) & mask, kp = ec > 0 ? (keys[ec - 1] >> shift) & mask : 0ull;
+  const int lm = valid ? oct_lmin(kp, kc, e == 0, depth) : OCT_MAXD + 2;
+  // level-L nodes opened before this wave, and the level's offset, in lane L's registers
+  uint32_t before_reg = 0, off_reg = 0;
+  if (lane < depth) {
+    before_reg = scan[(int64_t)lane * n_waves + w] - scan[(int64_t)lane * n_waves];
+    off_reg = offs[lane];
+  }
+  int lo = lm;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) lo = min(lo, __shfl_xor(lo, d, 64));
+  for (int L = max(lo - 1, 0); L < depth; ++L) {
+    const uint64_t m = __ballot(lm <= L);
+    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)before_reg, L);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)off_reg, L);
+    const bool opens = valid && lm <= L + 1;   // opens a node at level L+1: its octant goes into its level-L node
+    const uint32_t at = off + before + (uint32_t)__popcll(m & lanes_le) - 1u;
+    const uint32_t oct = (uint32_t)(kc >> (3 * (depth - L - 1))) & 7u;
+    // every lane knows the level-L node of its leaf (`at`), the lanes that open a child carry its bit: segmented OR
+    // towards the first lane of every run of equal word index (`at` ascends with the lane: runs are contiguous)
+    const uint32_t word = at >> 2;
+    uint32_t bits = opens ? (1u << oct) << (8u * (at & 3u)) : 0u;
+#pragma unroll
+    for (int d = 1; d <= 32; d <<= 1) {
+      const uint32_t ob = (uint32_t)__shfl_down((int)bits, d, 64), ow = (uint32_t)__shfl_down((int)word, d, 64);
+      bits |= (lane + d < 64 && ow == word) ? ob : 0u;
+    }
+    const uint32_t pw = (uint32_t)__shfl_up((int)word, 1, 64);
+    if (bits != 0u && (lane == 0 || pw != word)) atomicOr(&occ32[word], bits);
+  }
+}
+
+// Internal (octree2.hip): the levels of a large input and nothing read back — root-first packed into d_occ (4-byte
+// aligned, cap bytes), node counts of levels 0 .. depth-1 and the leaf count into d_counts[depth + 1].  A total above
+// cap leaves d_occ untouched.  Scratch from the arena behind what the caller has allocated (the caller reserves
+// pcc_octree_wave_scratch(n) bytes for it).
+size_t pcc_octree_wave_scratch(int64_t n) {
+  const int64_t n_waves = (n + 63) / 64;
+  return 2 * pcc_align((size_t)n_waves * OCT_MAXD * 4) + pcc_scan_scratch_bytes(n_waves * OCT_MAXD) + 4096;
+}
+int pcc_octree_wave_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,
+                          int64_t cap, uint32_t* d_counts) {
+  PCC_REQUIRE(ctx && d_keys && d_occ && d_counts && n >= 1 && n < ((int64_t)1 << 27) && depth >= 1 && depth <= 16 &&
+                  key_shift >= 0 && key_shift % 3 == 0 && key_shift + 3 * depth <= 48 && cap >= 4 &&
+                  (uintptr_t)d_occ % 4 == 0,
+              PCC_E_ARG, "pcc_octree_wave_async: bad argument (n=%lld depth=%d)", (long long)n, depth);
+  hipStream_t st = ctx->stream;
+  const int64_t n_waves = (n + 63) / 64, cells = n_waves * OCT_MAXD;
+  uint32_t* hist = (uint32_t*)pcc_arena_alloc(ctx, (size_t)cells * 4);
+  uint32_t* scan = (uint32_t*)pcc_arena_alloc(ctx, (size_t)cells * 4);
+  uint32_t* small = (uint32_t*)pcc_arena_alloc(ctx, 256);   // total | offs[17]
+  if (!hist || !scan || !small) return PCC_E_NOMEM;
+  uint32_t* total = small;
+  uint32_t* offs = small + 1;
+  const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
+  hipLaunchKernelGGL(k_octw_hist, dim3(nblk(n_waves, 4)), dim3(256), 0, st, d_keys, n, key_shift, leaf_mask, depth, n_waves, hist);
+  PCC_CHECK_LAUNCH();
+  PCC_TRY(pcc_scan_exclusive_u32(ctx, hist, scan, cells, total));
+  hipLaunchKernelGGL(k_octw_offsets, dim3(1), dim3(64), 0, st, (const uint32_t*)scan, (const uint32_t*)total, n_waves, depth,
+                     (uint32_t)n, d_counts, offs);
+  PCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_octw_zero, dim3(512), dim3(256), 0, st, (uint32_t*)d_occ, (const uint32_t*)offs, depth, cap / 4);
+  PCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_octw_emit, dim3(nblk(n_waves, 4)), dim3(256), 0, st, d_keys, n, key_shift, leaf_mask, depth, n_waves,
+                     (const uint32_t*)scan, (const uint32_t*)offs, (uint32_t*)d_occ, cap / 4 * 4);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 extern "C" int pcc_octree_levels(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift,
                                  int depth, uint8_t* d_occ, int64_t cap, int64_t* h_level_n) {
   PCC_REQUIRE(ctx && h_level_n, PCC_E_ARG, "pcc_octree_levels: null arg");
   PCC_REQUIRE(depth >= 1 && depth <= 16, PCC_E_ARG, "pcc_octree_levels: depth=%d", depth);
-  PCC_REQUIRE(n >= 1 && n < ((int64_t)1 << 31), PCC_E_ARG, "pcc_octree_levels: n=%lld", (long long)n);
+  PCC_REQUIRE(n >= 1 && n < ((int64_t)1 << 27), PCC_E_ARG, "pcc_octree_levels: n=%lld", (long long)n);
   PCC_REQUIRE(d_keys && d_occ, PCC_E_ARG, "pcc_octree_levels: null buffers");
   PCC_REQUIRE(key_shift >= 0 && key_shift % 3 == 0 && key_shift + 3 * depth <= 48, PCC_E_ARG,
               "pcc_octree_levels: key_shift=%d depth=%d", key_shift, depth);
   hipStream_t st = ctx->stream;
-  const size_t n8 = pcc_align((size_t)n * 8), n4 = pcc_align((size_t)n * 4), n1 = pcc_align((size_t)n);
-  PCC_TRY(pcc_arena_reserve(ctx, 2 * n8 + 2 * n4 + (size_t)depth * n1 + pcc_scan_scratch_bytes(n) + 4096));
-  uint64_t* buf_a = (uint64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
-  uint64_t* buf_b = (uint64_t*)pcc_arena_alloc(ctx, (size_t)n * 8);
-  uint32_t* flags = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
-  uint32_t* excl = (uint32_t*)pcc_arena_alloc(ctx, (size_t)n * 4);
-  uint8_t* occ_lv = (uint8_t*)pcc_arena_alloc(ctx, (size_t)depth * n1);
+  const size_t n1 = pcc_align((size_t)n);
+  const size_t cap_s = (size_t)depth * n1;   // bytes of the assembled levels (n * depth always suffices)
+  PCC_TRY(pcc_arena_reserve(ctx, cap_s + pcc_octree_wave_scratch(n) + 4096));
+  uint8_t* occ_lv = (uint8_t*)pcc_arena_alloc(ctx, cap_s);
   uint32_t* counts = (uint32_t*)pcc_arena_alloc(ctx, (size_t)(depth + 1) * 4);  // counts[L] = nodes at level L
-  if (!buf_a || !buf_b || !flags || !excl || !occ_lv || !counts) return PCC_E_NOMEM;
-  const size_t mark = ctx->arena_off;
+  if (!occ_lv || !counts) return PCC_E_NOMEM;
   PccProfScope prof(ctx, "octree_levels", n, depth, 0, 0);
-  const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
-
   if (n <= OCT_SMALL_MAX) {
-    // one launch; levels packed root-first from occ_lv[0], one read-back, one copy
-    const int cap_s = (int)((size_t)depth * n1);
+    const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
     hipLaunchKernelGGL(k_oct_small, dim3(1), dim3(OCT_T), 0, st, d_keys, (int)n, key_shift, leaf_mask, depth,
-                       (uint32_t*)occ_lv, cap_s, counts);
+                       (uint32_t*)occ_lv, (int)cap_s, counts);
     PCC_CHECK_LAUNCH();
-    uint32_t* hc = (uint32_t*)ctx->pinned;
-    PCC_HIP(hipMemcpyAsync(hc, counts, (size_t)(depth + 1) * 4, hipMemcpyDeviceToHost, st));
-    PCC_HIP(hipStreamSynchronize(st));
-    int64_t tot = 0;
-    for (int L = 0; L < depth; ++L) {
-      h_level_n[L] = (int64_t)hc[L];
-      tot += h_level_n[L];
-    }
-    PCC_REQUIRE(h_level_n[0] == 1, PCC_E_ARG,
-                "pcc_octree_levels: keys exceed 3*depth bits (root level has %lld nodes)",
-                (long long)h_level_n[0]);
-    PCC_REQUIRE(tot <= cap, PCC_E_ARG, "pcc_octree_levels: d_occ capacity %lld < %lld", (long long)cap,
-                (long long)tot);
-    PCC_REQUIRE(tot <= cap_s, PCC_E_ARG, "pcc_octree_levels: %lld nodes for %lld leaves", (long long)tot, (long long)n);
-    PCC_HIP(hipMemcpyAsync(d_occ, occ_lv, (size_t)tot, hipMemcpyDeviceToDevice, st));
-    return PCC_OK;
+  } else {
+    PCC_REQUIRE(cap_s < ((size_t)1 << 32), PCC_E_ARG, "pcc_octree_levels: %lld leaves at depth %d", (long long)n, depth);
+    PCC_TRY(pcc_octree_wave_async(ctx, d_keys, n, key_shift, depth, occ_lv, (int64_t)cap_s, counts));
   }
-
-  hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, counts + depth, (uint32_t)n);
-  PCC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_oct_leaves, dim3(nblk(n, 256)), dim3(256), 0, st, d_keys, n, key_shift,
-                     (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1)), buf_b);
-  PCC_CHECK_LAUNCH();
-  const uint64_t* cur = buf_b;
-  uint64_t* nxt = buf_a;
-  for (int L = depth - 1; L >= 0; --L) {
-    // children live at level L+1 (count counts[L+1]); their parents are level L
-    hipLaunchKernelGGL(k_oct_flags, dim3(nblk(n, 256)), dim3(256), 0, st, cur,
-                       (const uint32_t*)(counts + L + 1), n, flags);
-    PCC_CHECK_LAUNCH();
-    ctx->arena_off = mark;
-    PCC_TRY(pcc_scan_exclusive_u32(ctx, flags, excl, n, counts + L));
-    hipLaunchKernelGGL(k_oct_emit, dim3(nblk(n, 256)), dim3(256), 0, st, cur,
-                       (const uint32_t*)(counts + L + 1), (const uint32_t*)flags,
-                       (const uint32_t*)excl, nxt, occ_lv + (size_t)L * n1);
-    PCC_CHECK_LAUNCH();
-    cur = nxt;
-    nxt = (nxt == buf_a) ? buf_b : buf_a;
-  }
-  uint32_t* h = (uint32_t*)ctx->pinned;
-  PCC_HIP(hipMemcpyAsync(h, counts, (size_t)(depth + 1) * 4, hipMemcpyDeviceToHost, st));
+  // one read-back (the counts), one copy (the caller's array need not be aligned)
+  uint32_t* hc = (uint32_t*)ctx->pinned;
+  PCC_HIP(hipMemcpyAsync(hc, counts, (size_t)(depth + 1) * 4, hipMemcpyDeviceToHost, st));
   PCC_HIP(hipStreamSynchronize(st));
-  int64_t total = 0;
+  int64_t tot = 0;
   for (int L = 0; L < depth; ++L) {
-    h_level_n[L] = (int64_t)h[L];
-    total += h_level_n[L];
+    h_level_n[L] = (int64_t)hc[L];
+    tot += h_level_n[L];
   }
   PCC_REQUIRE(h_level_n[0] == 1, PCC_E_ARG,
               "pcc_octree_levels: keys exceed 3*depth bits (root level has %lld nodes)",
               (long long)h_level_n[0]);
-  PCC_REQUIRE(total <= cap, PCC_E_ARG, "pcc_octree_levels: d_occ capacity %lld < %lld",
-              (long long)cap, (long long)total);
-  int64_t off = 0;
-  for (int L = 0; L < depth; ++L) {
-    PCC_HIP(hipMemcpyAsync(d_occ + off, occ_lv + (size_t)L * n1, (size_t)h_level_n[L],
-                           hipMemcpyDeviceToDevice, st));
-    off += h_level_n[L];
-  }
+  PCC_REQUIRE(tot <= cap, PCC_E_ARG, "pcc_octree_levels: d_occ capacity %lld < %lld", (long long)cap,
+              (long long)tot);
+  PCC_REQUIRE(tot <= (int64_t)cap_s, PCC_E_ARG, "pcc_octree_levels: %lld nodes for %lld leaves", (long long)tot, (long long)n);
+  PCC_HIP(hipMemcpyAsync(d_occ, occ_lv, (size_t)tot, hipMemcpyDeviceToDevice, st));
   return PCC_OK;
 }

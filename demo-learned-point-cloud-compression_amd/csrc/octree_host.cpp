@@ -139,7 +139,7 @@ extern "C" int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, i
 
 extern "C" int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points, int* h_depth,
                                int32_t* h_origin) {
-  if (!h_in || len < kHeader || h_in[0] != 'O' || h_in[1] != 1 || h_in[2] > 16) {
+  if (!h_in || len < kHeader || h_in[0] != 'O' || (h_in[1] != 1 && h_in[1] != 2) || h_in[2] > 16) {
     pcc_set_error("pcc_octree_peek: not an octree blob (len=%lld)", (long long)len);
     return PCC_E_STREAM;
   }
@@ -185,6 +185,10 @@ static int octree_decode_cells(const uint8_t* h_in, int64_t len, std::vector<uin
   if (r != PCC_OK) return r;
   cells->clear();
   if (n == 0) return PCC_OK;
+  if (h_in[1] != 1) {   // blob version 2 is coded and decoded by the GPU (octree2.hip): there is no host decoder for it
+    pcc_set_error("pcc_octree_unpack: blob version %d needs a context (pcc_octree_decode_ctx / pcc_octree_decode_dev)", h_in[1]);
+    return PCC_E_STREAM;
+  }
   const uint8_t* p = h_in + kHeader;
   const uint8_t* end = p + get_u32(h_in + 20);
   auto word = [&](bool& bad) -> uint32_t {

@@ -41,3 +41,9 @@ struct pcc_rans_dev;
 int pcc_rans_encode_dev_async(pcc_ctx* ctx, const pcc_rans_dev* tables, const int32_t* d_sym, const uint8_t* d_idx,
                               int64_t idx_run, int64_t n, int n_streams, uint8_t* d_out, int64_t cap_each,
                               long long* d_lens, int attempt);
+
+// octree2.hip: blob version 2 of the geometry slot (levels, entropy coder and decoder on the GPU)
+int pcc_octree2_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, const int32_t origin[3],
+                       uint8_t* h_out, int64_t cap, int64_t* h_len);
+int pcc_octree2_decode(pcc_ctx* ctx, const uint8_t* h_in, int64_t len, int32_t* d_points, int32_t* h_points, int64_t cap_points,
+                       int64_t* h_n_points, int64_t* h_level_n);

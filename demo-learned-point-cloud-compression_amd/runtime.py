@@ -512,6 +512,33 @@ class Runtime:
         ln = [int(v) for v in level_n]
         return occ[:sum(ln)], ln
 
+    def octree_encode(self, keys, key_shift, version=0):
+        """geometry blob of one frame's Morton-sorted keys (pcc_octree_encode_version): version 0 = the library's rule —
+        blob version 2 (occupancy coder on the GPU, csrc/octree2.hip) above PCC_OCTREE_V2_MIN_LEAVES leaves, version 1
+        (serial host coder) below"""
+        n = keys.shape[0]
+        cap = 4096 + 17 * max(n, 1)          # one byte per node at most, plus header and chunk table
+        out = np.empty(cap, dtype=np.uint8)
+        length = C.c_int64(0)
+        check(self.lib.pcc_octree_encode_version(self.ctx, _ptr(keys), n, key_shift, version, _np_ptr(out), cap,
+                                                 C.byref(length)), "pcc_octree_encode")
+        return out[:length.value].tobytes()
+
+    def octree_decode(self, blob):
+        """blob (either version) -> int32 [n,3] host array, Morton order (pcc_octree_decode_ctx: version 2 is decoded
+        by the GPU)"""
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        n = C.c_int64(0)
+        check(self.lib.pcc_octree_decode_ctx(self.ctx, _np_ptr(buf), buf.shape[0], None, 0, C.byref(n)), "pcc_octree_decode_ctx")
+        pts = np.empty((n.value, 3), dtype=np.int32)
+        if n.value:
+            check(self.lib.pcc_octree_decode_ctx(self.ctx, _np_ptr(buf), buf.shape[0], _np_ptr(pts), n.value, C.byref(n)),
+                  "pcc_octree_decode_ctx")
+        return pts
+
+
+OCTREE_V2_MIN_LEAVES = 65536     # include/pcc.h PCC_OCTREE_V2_MIN_LEAVES
+
 
 # ---------------------------------------------------------------- GPU coder (container version 1)
 class RansDev:

@@ -141,6 +141,9 @@ def gpcc_encode_begin(keys_dev, keys_host, lo, hi, key_shift, slot=0):
     n = hi - lo
     if n == 0:
         return lambda: _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
+    if n > _rt.OCTREE_V2_MIN_LEAVES:     # blob version 2: the entropy coder runs on the GPU too, nothing left for the host
+        blob = rt.octree_encode(keys_dev[lo:hi], key_shift)
+        return lambda: blob
     first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
     depth, origin = octree_depth_origin(first, last, key_shift)
     occ, level_n = rt.octree_levels(keys_dev[lo:hi], key_shift, depth)
@@ -152,11 +155,15 @@ def gpcc_encode(keys_dev, keys_host, lo, hi, key_shift):
     """Lossless geometry blob for rows [lo,hi) of a Morton-sorted key array.
     Stands in for utils.gpcc_encode (shared/utils.py:169-207): the reference
     writes an ASCII PLY of `points/8` and shells out to tmc3; here the device
-    builds the octree occupancy bytes and the host entropy-codes them."""
+    builds the octree occupancy bytes and the host entropy-codes them — above
+    PCC_OCTREE_V2_MIN_LEAVES leaves (BASELINE.json configs[2]: a LiDAR sweep) the GPU
+    entropy-codes them too (blob version 2, csrc/octree2.hip)."""
     rt = _rt.current()
     n = hi - lo
     if n == 0:
         return _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
+    if n > _rt.OCTREE_V2_MIN_LEAVES:
+        return rt.octree_encode(keys_dev[lo:hi], key_shift)
     first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
     depth, origin = octree_depth_origin(first, last, key_shift)
     occ, level_n = rt.octree_levels(keys_dev[lo:hi], key_shift, depth)
@@ -165,5 +172,8 @@ def gpcc_encode(keys_dev, keys_host, lo, hi, key_shift):
 
 def gpcc_decode(data, scale=8):
     """blob -> int32 [n,3] coordinates (lattice units * scale), Morton order.
-    Stands in for utils.gpcc_decode (shared/utils.py:210-240; `* 8` at :235)."""
+    Stands in for utils.gpcc_decode (shared/utils.py:210-240; `* 8` at :235).
+    Version-2 blobs are decoded by the GPU (the active Runtime's context)."""
+    if len(data) >= 2 and data[1] == 2:
+        return _rt.current().octree_decode(data) * np.int32(scale)
     return _rt.octree_unpack(data) * np.int32(scale)

@@ -504,6 +504,32 @@ int pcc_octree_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
 int pcc_octree_decode(const uint8_t* h_in, int64_t len, int32_t* h_points,
                       int64_t cap_points, int64_t* h_n_points);
 
+/* Blob version 2 (round 4; csrc/octree2.hip gives the layout): the occupancy
+ * ENTROPY coder on the GPU too — the adaptive binary model of version 1, coded
+ * by 64 rANS states per wave over runs of consecutive nodes, every state's
+ * model starting from the frame's average probabilities (header).  BASELINE.json
+ * configs[2] (geometry-only coding of a ~100k-point LiDAR sweep) is this path.
+ * pcc_octree_encode writes version 2 for sets above PCC_OCTREE_V2_MIN_LEAVES
+ * leaves and version 1 (serial host coder: fewer bytes on small sets, and what
+ * the latent-sized slots of the codec use) below; _version forces one
+ * (0 = that rule).  Version-2 blobs are DEcoded by the GPU as well and have no
+ * host decoder: pcc_octree_decode / pcc_octree_unpack* refuse them with
+ * PCC_E_STREAM, the forms below take a context and read both versions.
+ *   _decode_ctx : points to the host (h_points NULL: only the count)
+ *   _decode_dev : points left in HBM (int32 [n,3], Morton order, origin added);
+ *                 h_level_n (16 entries, nullable) = nodes per octree level */
+#define PCC_OCTREE_V2_MIN_LEAVES 65536
+int pcc_octree_encode_version(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                              int key_shift, int version, uint8_t* h_out,
+                              int64_t cap, int64_t* h_len);
+int pcc_octree_blob_version(const uint8_t* h_in, int64_t len);
+int pcc_octree_decode_ctx(pcc_ctx* ctx, const uint8_t* h_in, int64_t len,
+                          int32_t* h_points, int64_t cap_points,
+                          int64_t* h_n_points);
+int pcc_octree_decode_dev(pcc_ctx* ctx, const uint8_t* h_in, int64_t len,
+                          int32_t* d_points, int64_t cap_points,
+                          int64_t* h_n_points, int64_t* h_level_n);
+
 /* ---- whole-GOP entry points ------------------------------ */
 
 /* replaces: CompressionPipeline.compress() (sender/encoder/codec_pipeline.py:

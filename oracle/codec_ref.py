@@ -47,6 +47,7 @@ class Oracle:
         self.lib.orc_topk.restype = C.c_int64
         self.lib.orc_rans_encode.restype = C.c_int64
         self.lib.orc_octree_encode.restype = C.c_int64
+        self.lib.orc_octree2_encode.restype = C.c_int64
         self.lib.orc_octree_decode.restype = C.c_int64
         with np.load(ckpt) as f:
             self.t = {k: f[k] for k in f.files}
@@ -252,11 +253,17 @@ class Oracle:
             raise ValueError(f"interleaved rANS stream: decode error {r}")
         return sym
 
-    def octree_encode(self, points, bias):
+    OCTREE_V2_MIN_LEAVES = 65536     # include/pcc.h PCC_OCTREE_V2_MIN_LEAVES: larger sets take blob version 2
+
+    def octree_encode(self, points, bias, version=None):
+        """version None: the product's rule (blob version 2, the GPU-coded form, above 65536 leaves)"""
         points = np.ascontiguousarray(points, dtype=np.int32)
-        cap = 64 + 16 * points.shape[0] * 2 + 64
+        if version is None:
+            version = 2 if points.shape[0] > self.OCTREE_V2_MIN_LEAVES else 1
+        cap = 1024 + 16 * points.shape[0] * 2 + 64
         out = np.empty(cap, dtype=np.uint8)
-        n = self.lib.orc_octree_encode(_p(points), C.c_int64(points.shape[0]), C.c_int(bias), _p(out), C.c_int64(cap))
+        fn = self.lib.orc_octree2_encode if version == 2 else self.lib.orc_octree_encode
+        n = fn(_p(points), C.c_int64(points.shape[0]), C.c_int(bias), _p(out), C.c_int64(cap))
         assert n >= 0
         return out[:n].tobytes()
 

@@ -674,9 +674,262 @@ ORC_API int64_t orc_octree_encode(const int32_t* points, int64_t n, int bias, ui
   return ret;
 }
 
+
+/* ---------------------------------------------------- octree, blob version 2 */
+
+/* Blob version 2 of the `points` slot: the SAME adaptive binary model as version 1 (context = level class, bit
+ * position, ones so far; 12-bit probabilities, adaptation shift 4), coded by many rANS states at once so that the
+ * GPU codes and decodes it (csrc/octree2.hip) — north_star's "octree occupancy ... hand-written HIP".  What changes
+ * against version 1: (i) the nodes (breadth-first, root first) are dealt in runs of S consecutive nodes to the 64
+ * lanes of chunks, each lane with its own 32-bit rANS state (L = 2^16, 16-bit words) and its own copy of the model;
+ * (ii) every lane's model starts from the frame's average probability per context (p0, in the header) instead of
+ * 1/2; (iii) the node count of every level is in the header (a decoder needs the level class of a node before it
+ * has decoded the levels above it).
+ *   'O' 2 depth 0 | u32 n | i32 origin[3] | u32 payload_len |
+ *   u32 level_n[depth] | u32 S | u32 n_chunks | u16 p0[108] | u32 words[n_chunks] | chunk payloads (16-bit words)
+ *   chunk c, lane l: nodes [(64 c + l) S, (64 c + l + 1) S) below n_nodes = sum(level_n)
+ *   step t = 8 s + j of a chunk: every lane codes bit j of its node s (nothing when the node does not exist or the
+ *   bit is implied: j == 7 after seven zeros)
+ *   payload = 64 x (state lo, state hi) | block(step 0) | block(step 1) ..: a block holds the 16-bit words the
+ *   decoder's lanes need after that step, in ascending lane order.
+ * The encoder walks the steps backwards, lanes in descending order, and fills the chunk from its end. */
+#define O2_LANES 64
+#define O2_SMAX 512
+#define O2_CTX 108
+static int o2_cls(int64_t node, int64_t start_last, int64_t start_prev) { return node >= start_last ? 0 : (node >= start_prev ? 1 : 2); }
+static uint32_t o2_p0(uint64_t c0, uint64_t c1) {
+  uint64_t p = (4096ull * (2 * c1 + 1)) / (2 * (c0 + c1 + 1));
+  return (uint32_t)(p < 16 ? 16 : (p > 4080 ? 4080 : p));
+}
+static void o2_layout(int64_t n_nodes, int64_t* S, int64_t* nc) {
+  int64_t c = (n_nodes + O2_LANES * O2_SMAX - 1) / (O2_LANES * O2_SMAX); if (c < 1) c = 1;
+  int64_t s = (n_nodes + O2_LANES * c - 1) / (O2_LANES * c);
+  s = (s + 3) / 4 * 4; if (s < 4) s = 4;
+  *S = s; *nc = c;
+}
+
+/* occupancy bytes, breadth-first, of the points (as orc_octree_encode finds them); returns n_nodes */
+static int64_t o2_bytes(const int32_t* points, int64_t n, int bias, int* depth_out, int32_t origin[3], uint8_t** occ_out,
+                        int64_t level_n[16]) {
+  uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+  for (int64_t i = 0; i < n; ++i)
+    keys[i] = (part3((uint32_t)(points[3 * i] + bias)) << 2) | (part3((uint32_t)(points[3 * i + 1] + bias)) << 1) |
+              part3((uint32_t)(points[3 * i + 2] + bias));
+  qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64);
+  int depth = 1;
+  { uint64_t diff = keys[0] ^ keys[n - 1]; int msb = -1; while (diff) { ++msb; diff >>= 1; } if (msb >= 0) depth = msb / 3 + 1; }
+  const uint64_t corner = (keys[0] >> (3 * depth)) << (3 * depth);
+  origin[0] = (int32_t)unpart3(corner >> 2) - bias; origin[1] = (int32_t)unpart3(corner >> 1) - bias; origin[2] = (int32_t)unpart3(corner) - bias;
+  for (int64_t i = 0; i < n; ++i) keys[i] -= corner;
+  uint8_t* occ = (uint8_t*)malloc((size_t)(n * depth + 8));
+  int64_t nn = 0;
+  for (int L = 0; L < depth; ++L) {
+    const int node_shift = 3 * (depth - L), child_shift = node_shift - 3;
+    int64_t i = 0, cnt = 0;
+    while (i < n) {
+      const uint64_t node = keys[i] >> node_shift;
+      unsigned byte = 0; int64_t j = i;
+      while (j < n && (keys[j] >> node_shift) == node) { byte |= 1u << (unsigned)((keys[j] >> child_shift) & 7ull); ++j; }
+      occ[nn++] = (uint8_t)byte; ++cnt; i = j;
+    }
+    level_n[L] = cnt;
+  }
+  free(keys);
+  *depth_out = depth; *occ_out = occ;
+  return nn;
+}
+
+ORC_API int64_t orc_octree2_encode(const int32_t* points, int64_t n, int bias, uint8_t* out, int64_t cap) {
+  if (cap < 24) return -1;
+  memset(out, 0, 24);
+  out[0] = 'O'; out[1] = 2;
+  w32(out + 4, (uint32_t)n);
+  if (n == 0) return 24;
+  int depth; int32_t origin[3]; uint8_t* occ; int64_t level_n[16];
+  const int64_t n_nodes = o2_bytes(points, n, bias, &depth, origin, &occ, level_n);
+  out[2] = (uint8_t)depth;
+  for (int a = 0; a < 3; ++a) w32(out + 8 + 4 * a, (uint32_t)origin[a]);
+  int64_t S, nc; o2_layout(n_nodes, &S, &nc);
+  const int64_t start_last = n_nodes - level_n[depth - 1];
+  const int64_t start_prev = depth >= 2 ? start_last - level_n[depth - 2] : 0;
+  /* the frame's average probability of a one per context */
+  uint64_t c0[O2_CTX], c1[O2_CTX];
+  memset(c0, 0, sizeof c0); memset(c1, 0, sizeof c1);
+  for (int64_t i = 0; i < n_nodes; ++i) {
+    const int cls = o2_cls(i, start_last, start_prev);
+    int ones = 0;
+    for (int j = 0; j < 8; ++j) {
+      const int bit = (occ[i] >> j) & 1;
+      if (j == 7 && ones == 0) break;
+      const int ctx = cls * 36 + j * (j + 1) / 2 + ones;
+      if (bit) c1[ctx]++; else c0[ctx]++;
+      ones += bit;
+    }
+  }
+  uint16_t p0[O2_CTX];
+  for (int i = 0; i < O2_CTX; ++i) p0[i] = (uint16_t)o2_p0(c0[i], c1[i]);
+  const int64_t head = 24 + 4 * depth + 8 + 2 * O2_CTX + 4 * nc;
+  if (cap < head) { free(occ); return -1; }
+  uint8_t* q = out + 24;
+  for (int L = 0; L < depth; ++L, q += 4) w32(q, (uint32_t)level_n[L]);
+  w32(q, (uint32_t)S); w32(q + 4, (uint32_t)nc); q += 8;
+  for (int i = 0; i < O2_CTX; ++i, q += 2) { q[0] = (uint8_t)p0[i]; q[1] = (uint8_t)(p0[i] >> 8); }
+  uint8_t* table = q;
+  int64_t pos = head;
+  const int64_t T = 8 * S, cw_cap = 2 * O2_LANES + O2_LANES * T;
+  uint16_t* buf = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cw_cap);
+  uint16_t* rec = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)(O2_LANES * T));   /* [t][lane]: p | bit << 15, 0 = nothing coded */
+  int64_t ret = 0;
+  for (int64_t c = 0; c < nc && ret == 0; ++c) {
+    for (int l = 0; l < O2_LANES; ++l) {
+      uint16_t model[O2_CTX];
+      memcpy(model, p0, sizeof model);
+      for (int64_t s = 0; s < S; ++s) {
+        const int64_t node = (O2_LANES * c + l) * S + s;
+        int ones = 0;
+        for (int j = 0; j < 8; ++j) {
+          uint16_t r = 0;
+          if (node < n_nodes && !(j == 7 && ones == 0)) {
+            const int bit = (occ[node] >> j) & 1;
+            uint16_t* m = &model[o2_cls(node, start_last, start_prev) * 36 + j * (j + 1) / 2 + ones];
+            r = (uint16_t)(*m | (bit << 15));
+            oct_adapt(m, bit);
+            ones += bit;
+          }
+          rec[(8 * s + j) * O2_LANES + l] = r;
+        }
+      }
+    }
+    uint32_t x[O2_LANES];
+    for (int l = 0; l < O2_LANES; ++l) x[l] = 1u << 16;
+    int64_t ptr = cw_cap;
+    for (int64_t t = T - 1; t >= 0; --t)
+      for (int l = O2_LANES - 1; l >= 0; --l) {
+        const uint16_t r = rec[t * O2_LANES + l];
+        if (!r) continue;
+        const uint32_t p1 = r & 0xFFFu, bit = r >> 15;
+        const uint32_t freq = bit ? p1 : 4096 - p1, start = bit ? 4096 - p1 : 0;
+        if ((uint64_t)x[l] >= ((uint64_t)freq << 20)) { buf[--ptr] = (uint16_t)x[l]; x[l] >>= 16; }
+        x[l] = ((x[l] / freq) << 12) + (x[l] % freq) + start;
+      }
+    ptr -= 2 * O2_LANES;
+    for (int l = 0; l < O2_LANES; ++l) { buf[ptr + 2 * l] = (uint16_t)x[l]; buf[ptr + 2 * l + 1] = (uint16_t)(x[l] >> 16); }
+    const int64_t cw = cw_cap - ptr;
+    if (pos + 2 * cw > cap) { ret = -1; break; }
+    w32(table + 4 * c, (uint32_t)cw);
+    for (int64_t k = 0; k < cw; ++k) { out[pos + 2 * k] = (uint8_t)buf[ptr + k]; out[pos + 2 * k + 1] = (uint8_t)(buf[ptr + k] >> 8); }
+    pos += 2 * cw;
+  }
+  free(rec); free(buf); free(occ);
+  if (ret < 0) return -1;
+  w32(out + 20, (uint32_t)(pos - 24));
+  return pos;
+}
+
+/* version-2 blob -> occupancy bytes (breadth-first); returns n_nodes or -1; level_n[16] filled */
+static int64_t o2_decode_bytes(const uint8_t* in, int64_t len, uint8_t** occ_out, int64_t level_n[16]) {
+  const int depth = in[2];
+  const int64_t n = (int64_t)r32(in + 4), payload = (int64_t)r32(in + 20);
+  if (depth < 1 || depth > 16 || 24 + payload > len) return -1;
+  const uint8_t* q = in + 24;
+  const uint8_t* end = in + 24 + payload;
+  if (payload < 4 * depth + 8 + 2 * O2_CTX) return -1;
+  int64_t n_nodes = 0;
+  for (int L = 0; L < depth; ++L, q += 4) { level_n[L] = (int64_t)r32(q); n_nodes += level_n[L]; }
+  const int64_t S = (int64_t)r32(q), nc = (int64_t)r32(q + 4); q += 8;
+  if (level_n[0] != 1 || S < 4 || S % 4 || S > 65532 || nc < 1 || O2_LANES * S * nc < n_nodes || O2_LANES * S * (nc - 1) >= n_nodes || n_nodes > n * depth) return -1;
+  uint16_t p0[O2_CTX];
+  for (int i = 0; i < O2_CTX; ++i, q += 2) { p0[i] = (uint16_t)(q[0] | (q[1] << 8)); if (p0[i] < 16 || p0[i] > 4080) return -1; }
+  if (end - q < 4 * nc) return -1;
+  const uint8_t* table = q;
+  const uint8_t* pl = q + 4 * nc;
+  const int64_t start_last = n_nodes - level_n[depth - 1];
+  const int64_t start_prev = depth >= 2 ? start_last - level_n[depth - 2] : 0;
+  uint8_t* occ = (uint8_t*)calloc((size_t)(n_nodes + 8), 1);
+  uint16_t* model = (uint16_t*)malloc(sizeof(uint16_t) * O2_LANES * O2_CTX);
+  int bad = 0;
+  for (int64_t c = 0; c < nc && !bad; ++c) {
+    const int64_t cw = (int64_t)r32(table + 4 * c);
+    if (cw < 2 * O2_LANES || end - pl < 2 * cw) { bad = 1; break; }
+    uint32_t x[O2_LANES];
+    int ones[O2_LANES];
+    for (int l = 0; l < O2_LANES; ++l) {
+      x[l] = (uint32_t)(pl[4 * l] | (pl[4 * l + 1] << 8)) | ((uint32_t)(pl[4 * l + 2] | (pl[4 * l + 3] << 8)) << 16);
+      memcpy(model + l * O2_CTX, p0, sizeof p0);
+    }
+    int64_t ptr = 2 * O2_LANES;
+    for (int64_t t = 0; t < 8 * S && !bad; ++t) {
+      const int64_t s = t >> 3; const int j = (int)(t & 7);
+      for (int l = 0; l < O2_LANES; ++l) {
+        const int64_t node = (O2_LANES * c + l) * S + s;
+        if (j == 0) ones[l] = 0;
+        if (node >= n_nodes) continue;
+        int bit;
+        if (j == 7 && ones[l] == 0) bit = 1;
+        else {
+          uint16_t* m = &model[l * O2_CTX + o2_cls(node, start_last, start_prev) * 36 + j * (j + 1) / 2 + ones[l]];
+          const uint32_t p1 = *m, cum = x[l] & 4095u;
+          bit = cum >= 4096 - p1;
+          const uint32_t start = bit ? 4096 - p1 : 0, freq = bit ? p1 : 4096 - p1;
+          x[l] = freq * (x[l] >> 12) + cum - start;
+          if (x[l] < (1u << 16)) {
+            if (ptr >= cw) { bad = 1; break; }
+            x[l] = (x[l] << 16) | (uint32_t)(pl[2 * ptr] | (pl[2 * ptr + 1] << 8));
+            ++ptr;
+          }
+          oct_adapt(m, bit);
+        }
+        if (bit) { occ[node] |= (uint8_t)(1u << j); ones[l]++; }
+      }
+    }
+    if (ptr != cw) bad = 1;
+    pl += 2 * cw;
+  }
+  free(model);
+  if (bad || pl != end) { free(occ); return -1; }
+  *occ_out = occ;
+  return n_nodes;
+}
+
+static int64_t orc_octree2_decode(const uint8_t* in, int64_t len, int32_t* points, int64_t cap_points) {
+  const int depth = in[2];
+  const int64_t n = (int64_t)r32(in + 4);
+  if (n == 0) return 0;
+  if (n > cap_points) return -1;
+  int32_t org[3];
+  for (int a = 0; a < 3; ++a) org[a] = (int32_t)r32(in + 8 + 4 * a);
+  uint8_t* occ; int64_t level_n[16];
+  const int64_t n_nodes = o2_decode_bytes(in, len, &occ, level_n);
+  if (n_nodes < 0) return -1;
+  uint64_t* cur = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n + 8));
+  uint64_t* nxt = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n + 8));
+  int64_t nc = 1, pos = 0, ret = n;
+  cur[0] = 0;
+  for (int L = 0; L < depth && ret >= 0; ++L) {
+    if (nc != level_n[L]) { ret = -1; break; }
+    int64_t nn = 0;
+    for (int64_t i = 0; i < nc && ret >= 0; ++i, ++pos) {
+      if (occ[pos] == 0) { ret = -1; break; }
+      for (int b = 0; b < 8; ++b)
+        if ((occ[pos] >> b) & 1) { if (nn >= n) { ret = -1; break; } nxt[nn++] = (cur[i] << 3) | (uint64_t)b; }
+    }
+    uint64_t* t = cur; cur = nxt; nxt = t; nc = nn;
+  }
+  if (ret >= 0 && nc != n) ret = -1;
+  if (ret >= 0)
+    for (int64_t i = 0; i < n; ++i) {
+      points[3 * i] = (int32_t)unpart3(cur[i] >> 2) + org[0];
+      points[3 * i + 1] = (int32_t)unpart3(cur[i] >> 1) + org[1];
+      points[3 * i + 2] = (int32_t)unpart3(cur[i]) + org[2];
+    }
+  free(cur); free(nxt); free(occ);
+  return ret;
+}
+
 /* returns number of points (Morton order), or -1 */
 ORC_API int64_t orc_octree_decode(const uint8_t* in, int64_t len, int32_t* points, int64_t cap_points) {
-  if (len < 24 || in[0] != 'O' || in[1] != 1) return -1;
+  if (len < 24 || in[0] != 'O' || (in[1] != 1 && in[1] != 2)) return -1;
+  if (in[1] == 2) return orc_octree2_decode(in, len, points, cap_points);
   const int depth = in[2];
   const int64_t n = (int64_t)r32(in + 4);
   if (n == 0) return 0;
