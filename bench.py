@@ -93,6 +93,103 @@ def cpu_baseline(wl, frame, n_sample, threads, runs=5, warmups=2):
                        f"restatement with OpenMP on {threads} threads")}, full
 
 
+def bench_configs(pkg, wl, device, threads, steps=5, warmup=2, with_oracle=True):
+    """The other configurations of BASELINE.json and the reference's own operating point, each timed on this GPU
+    after the headline (outside its timed region): `warmup` untimed + `steps` timed passes of the operator contract
+    (host numpy in / host numpy out, Q = 3 unless geometry-only), medians.  `equals_oracle`: containers (blob) and
+    reconstruction compared with the CPU oracle's on the same input — the checker, never the thing measured; None
+    where the oracle run is not affordable inside a bench run (C5: 4M points)."""
+    import torch
+    tiled = importlib.import_module(PKG + ".tiled")
+    utils = importlib.import_module(PKG + ".utils")
+    runtime = importlib.import_module(PKG + ".runtime")
+    oracle = None
+    if with_oracle:
+        from oracle.codec_ref import Oracle
+        oracle = Oracle(threads=threads)
+    q_dec = len(SETTINGS)
+    med = lambda v: float(np.median(np.asarray(v)))    # noqa: E731
+    res = {}
+
+    def codec_case(name, frames, what, check):
+        enc = pkg.CompressionPipeline(SETTINGS, device=device, slots=1)
+        dec = pkg.DecompressionPipeline(device=device, slots=1, output="numpy")
+        e_ms, d_ms = [], []
+        for it in range(warmup + steps):
+            gop = wl.gop([dict(f) for f in frames])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out, side = enc.compress(gop)
+            t1 = time.perf_counter()
+            rec, _ = dec.decompress(out[q_dec])
+            t2 = time.perf_counter()
+            if it >= warmup:
+                e_ms.append(1e3 * (t1 - t0))
+                d_ms.append(1e3 * (t2 - t1))
+        n_pts = int(sum(f["points"].shape[0] for f in frames))
+        same = None
+        if check and oracle is not None:
+            o_out, _ = oracle.compress([dict(f) for f in frames], SETTINGS)
+            o_rec = oracle.decompress(o_out[q_dec])
+            same = bool(all(out[q] == o_out[q] for q in range(1, q_dec + 1)) and len(rec) == len(o_rec) and
+                        all(np.array_equal(a["points"], b["points"]) and np.array_equal(a["colors"], b["colors"])
+                            for a, b in zip(rec, o_rec)))
+            assert same, f"{name}: HIP path and CPU oracle disagree"
+        res[name] = {"workload": what, "frames": len(frames), "points": n_pts, "encode_ms": med(e_ms), "decode_ms": med(d_ms),
+                     "gops_per_s": 1e3 / (med(e_ms) + med(d_ms)), "frames_per_s": 1e3 * len(frames) / (med(e_ms) + med(d_ms)),
+                     "bpp": [float(b) for b in side["gop_info"]["bpp"]], "steps": steps, "equals_oracle": same}
+        del enc, dec
+
+    codec_case("C1", [wl.sphere_shell(64, 25.2, seed=1)],
+               "BASELINE.json configs[0]: 64^3 sphere shell (~8k voxels), one frame", True)
+    # C3: geometry only — utils.gpcc_encode / gpcc_decode (shared/utils.py:169-240) from host int16 points to the blob on
+    # the host and back to host coordinates: upload, Morton keys, sort, octree levels + occupancy coder on the GPU
+    # (blob version 2, csrc/octree2.hip), decode on the GPU, download
+    sweep = wl.lidar_sweep()
+    pts = sweep["points"]
+    rt = runtime.Runtime(device)
+    with rt:
+        e_ms, d_ms, k_ms = [], [], []
+        for it in range(warmup + steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            coords = np.concatenate([np.zeros((pts.shape[0], 1), np.int32), pts.astype(np.int32)], 1)
+            keys = rt.morton_keys(rt.to_device(coords))
+            rt.sort_pairs(keys)
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            blob = utils.gpcc_encode(keys, None, 0, keys.shape[0], 0)
+            t1 = time.perf_counter()
+            dec_pts = utils.gpcc_decode(blob, 1)
+            t2 = time.perf_counter()
+            if it >= warmup:
+                e_ms.append(1e3 * (t1 - t0))
+                d_ms.append(1e3 * (t2 - t1))
+                k_ms.append(1e3 * (tk - t0))
+        same = None
+        if oracle is not None:
+            same = bool(blob == oracle.octree_encode(pts.astype(np.int32), 32768) and
+                        np.array_equal(dec_pts, oracle.octree_decode(blob)))
+            assert same, "C3: HIP blob / decoded points differ from the oracle's"
+        res["C3"] = {"workload": "BASELINE.json configs[2]: KITTI-like LiDAR sweep, geometry-only octree occupancy coding "
+                                 "(lossless), host int16 points -> blob -> host int32 points",
+                     "frames": 1, "points": int(pts.shape[0]), "encode_ms": med(e_ms), "decode_ms": med(d_ms),
+                     "encode_ms_keys_and_sort": med(k_ms), "frames_per_s": 1e3 / (med(e_ms) + med(d_ms)),
+                     "bpp": [8.0 * len(blob) / pts.shape[0]], "blob_version": int(blob[1]), "steps": steps, "equals_oracle": same}
+    rt.close()
+    codec_case("C4", [wl.body(800_000)], "BASELINE.json configs[3]: 8iVFB-like dense body with RGB, 800k voxels, one frame", True)
+    tiles, _ = tiled.cut_tiles(wl.fused_scan(4_000_000), (512, 512, 256))
+    codec_case("C5_one_gpu", tiles, "BASELINE.json configs[4] on ONE GPU: 4M-point fused scan cut into 8 octree blocks of 500k "
+                                    "voxels, the 8 blocks coded as the 8 frames of one GOP (the N-GPU form deals them to ranks)", False)
+    del tiles
+    with np.load(os.path.join(ROOT, "tests", "golden", "zed_seq25.npz")) as f:
+        zed = [{"points": f[f"points_{i}"], "colors": f[f"colors_u8_{i}"].astype(np.float64) / 255.0} for i in range(5)]
+    codec_case("zed_gop5", zed, "the reference's operating point: GOP of 5 recorded ZED frames (evaluation/data/test_sequence, the "
+                                "first five its encoder service samples), Q = 3; the reference logs 841 ms encode / 715 ms decode "
+                                "per 66k-point GOP on a Jetson AGX Orin (BASELINE.md: other hardware, other weights)", True)
+    return res
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it (the driver's command): start the N ranks here, one
     fresh child process per GPU, with the environment torch.distributed.run would give them.  This parent never
@@ -149,6 +246,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="also report throughput with this many GOPs in flight (0/1 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C4 / C5-on-one-GPU / ZED-GOP entries")
+    ap.add_argument("--config-steps", type=int, default=5)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -474,6 +573,14 @@ def main():
             assert quality["oracle"] == quality["hip"]
         log(f"distortion figures in {time.time() - t0:.1f}s:", quality)
 
+    configs = None
+    if rank == 0 and not tiled_mode and not args.no_configs:
+        abi = importlib.import_module(PKG + "._abi")
+        t0 = time.time()
+        configs = bench_configs(pkg, wl, local, abi.host_cpu_budget(), steps=args.config_steps,
+                                with_oracle=not args.no_cpu_baseline)
+        log(f"configs in {time.time() - t0:.1f}s:", json.dumps(configs))
+
     if rank == 0:
         frames_total = args.steps * world
         if not tiled_mode:
@@ -535,6 +642,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "throughput_in_flight": inflight,
+            "configs": configs,
         }
         if line["ranks_seen"] != line["n_gpus"] or line["n_gpus"] != args.gpus:
             sys.exit(f"bench.py: {line['ranks_seen']} ranks seen for --gpus {args.gpus}: no line printed")

@@ -162,7 +162,7 @@ def gpcc_encode(keys_dev, keys_host, lo, hi, key_shift):
     n = hi - lo
     if n == 0:
         return _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
-    if n > _rt.OCTREE_V2_MIN_LEAVES:
+    if keys_host is None or n > _rt.OCTREE_V2_MIN_LEAVES:   # one library call (it reads the two end keys itself)
         return rt.octree_encode(keys_dev[lo:hi], key_shift)
     first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
     depth, origin = octree_depth_origin(first, last, key_shift)

@@ -62,3 +62,23 @@ def test_rccl_on_a_one_gpu_box_is_refused():
     r = _run(["--gpus", "2", "--points", "60000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-psnr"])
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "needs 2 GPUs" in r.stderr
+
+
+@pytest.mark.gpu
+def test_driver_line_carries_every_config():
+    """the N = 1 line: headline fields of the contract, roofline + cpu_baseline objects, and one entry per BASELINE.json
+    configuration beside the headline's (C1, C3, C4, C5 on one GPU) plus the reference's operating point (a GOP of 5
+    recorded ZED frames), the affordable ones checked against the oracle inside the run"""
+    r = _run(["--steps", "2", "--warmup", "1", "--points", "60000", "--cpu-runs", "1", "--inflight", "0", "--config-steps", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    cfg = line["configs"]
+    assert set(cfg) == {"C1", "C3", "C4", "C5_one_gpu", "zed_gop5"}
+    for name, c in cfg.items():
+        assert c["encode_ms"] > 0 and c["decode_ms"] > 0 and c["frames_per_s"] > 0 and c["bpp"], name
+    assert all(cfg[k]["equals_oracle"] is True for k in ("C1", "C3", "C4", "zed_gop5"))
+    assert cfg["C3"]["blob_version"] == 2 and cfg["C5_one_gpu"]["frames"] == 8 and cfg["zed_gop5"]["frames"] == 5
