@@ -82,10 +82,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   // step, reads "no neighbour" there, with no compare in the step
   __shared__ __attribute__((aligned(4))) unsigned char lut[27 * 8];
 
-#ifdef PCCUP_FAT_LDS   // diagnostic: one wave per SIMD (4 workgroups per CU)
-  __shared__ float fat_lds[5000];
-  if (in_bytes == 12345u) fat_lds[threadIdx.x] = 1.f;
-#endif
   const int lane = threadIdx.x;
   const int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware order (conv16.h)
   const int64_t par0 = window * 16;
@@ -102,9 +98,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)in_bytes, 0x00027000);
 
   auto load_w = [&](float4 (&W)[4], int k) {
-#ifdef PCCUP_ABL_W0    // timing ablation: four offsets' weights for all (L1-resident; the mask is 3 at run time, opaque at compile time)
-    k &= 3 + 28 * (int)(in_bytes >> 31);
-#endif
     const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wsw + (int64_t)k * 1024) + (uint32_t)lane * 64u);
 #pragma unroll
     for (int j = 0; j < 4; ++j) W[j] = p[j];
@@ -139,9 +132,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     }
   };
   auto acc_read = [&](int arow, f32x4& lo, f32x4& hi) {
-#ifdef PCCUP_ABL_NOACC   // timing ablation: the remainder's tiles never come from LDS
-    if (arow != 0x7fffffff) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; return; }
-#endif
     const float* base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(acc_lds) + (arow ^ q16));
     const float4 a = *reinterpret_cast<const float4*>(base);
     const float4 b = *reinterpret_cast<const float4*>(base + HP);
@@ -149,9 +139,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     hi[0] = b.x; hi[1] = b.y; hi[2] = b.z; hi[3] = b.w;
   };
   auto acc_write = [&](int arow, const f32x4& lo, const f32x4& hi) {
-#ifdef PCCUP_ABL_NOACC
-    if (arow != a_sink) { if (lo[0] == 1.2345f) acc_lds[0] = hi[0]; return; }
-#endif
     float* base = reinterpret_cast<float*>(reinterpret_cast<char*>(acc_lds) + (arow ^ q16));
     *reinterpret_cast<float4*>(base) = make_float4(lo[0], lo[1], lo[2], lo[3]);
     *reinterpret_cast<float4*>(base + HP) = make_float4(hi[0], hi[1], hi[2], hi[3]);
@@ -212,9 +199,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
 #endif
 
   // ---- 1. siblings: dense product over the window's 16 parents (slot n = parent par0 + n)
-#ifdef PCCUP_PRIO_DENSE
-  __builtin_amdgcn_s_setprio(PCCUP_PRIO_DENSE);
-#endif
   {
     float xs[8][8];
     {
@@ -242,10 +226,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     float4 Wd[WD + 1][4];
 #pragma unroll
     for (int k = 0; k < WD; ++k) load_w(Wd[k], k);
-#ifndef PCCUP_NO_DENSE   // timing ablations only (tools/ab_build.sh): wrong results
-#ifdef PCCUP_DENSE2
-    for (int rep = 0; rep < 2 + (int)(in_bytes >> 31); ++rep)
-#endif
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
       if (k + WD < 27) load_w(Wd[(k + WD) % (WD + 1)], k + WD);
@@ -267,7 +247,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     PCC_STAMP(2);   // sibling product
     // the tiles seed the accumulators of the remainder: lane (n, q) holds channels 4q .. (+16) of row 8 n + o
 #pragma unroll
@@ -280,9 +259,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       if (e < 27 * 16) pb[e] = have ? pbv[i] : -1;
     }
     if (lane < 54) reinterpret_cast<uint32_t*>(lut)[lane] = reinterpret_cast<const uint32_t*>(kPccUpLut.b)[lane];
-#ifdef PCCUP_FAT_LDS
-    if (in_bytes == 12345u) acc_lds[lane] = fat_lds[lane ^ 1];
-#endif
   }
 
   // ---- 2. remainder
@@ -301,11 +277,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       racc[g] = r.y;
     }
   };
-#ifdef PCCUP_ABL_NEAR   // timing ablation: every gather from 16 KB of L1-resident rows
-  auto gather = [&](int g) { load_row((uint32_t)rin[g] & 0x3FE0u, G[g][0], G[g][1]); };
-#else
   auto gather = [&](int g) { load_row((uint32_t)rin[g], G[g][0], G[g][1]); };
-#endif
   auto resolve = [&](int (&racc)[NI]) {
 #pragma unroll
     for (int g = 0; g < NI; ++g) {
@@ -317,34 +289,16 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     }
     asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(cb));   // requested with the records, arrived with them
   };
-#ifdef PCCUP_ABL_NO123   // timing ablations: items 1 .. 3 never / all four items always
-#define PCCUP_LIVE(g) (cnt_cur > 16 * (g) + 1000000)
-#elif defined(PCCUP_ABL_ALL4)
-#define PCCUP_LIVE(g) true
-#elif defined(PCCUP_MINLIVE)   // items below PCCUP_MINLIVE run whether or not the offset has rows for them (pad slots: exact)
-#define PCCUP_LIVE(g) ((g) < PCCUP_MINLIVE || cnt_cur > 16 * (g))
-#else
-#define PCCUP_LIVE(g) (cnt_cur > 16 * (g))
-#endif
+#define UP_LIVE(g) (cnt_cur > 16 * (g))
   int cnt_cur;
-#ifdef PCCUP_FILL_LOC   // timing ablation: eight independent register-only MFMAs at ONE place of the step — is there a stall to hide them in?
-  f32x4 fill_l = {0.f, 0.f, 0.f, 0.f}, fill_h = {1.f, 0.f, 0.f, 0.f};
-#define PCCUP_FILL_AT(loc) do { if constexpr ((loc) == PCCUP_FILL_LOC) { __builtin_amdgcn_sched_barrier(0); \
-      _Pragma("unroll") for (int f = 0; f < 8; ++f) { \
-        if (f & 1) fill_h = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[f & 7], wl[(f + 3) & 7], fill_h, 0, 0, 0); \
-        else fill_l = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[f & 7], wh[(f + 3) & 7], fill_l, 0, 0, 0); } \
-      __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define PCCUP_FILL_AT(loc) do { } while (0)
-#endif
   auto step = [&](int j, float4 (&Wc)[4], float4 (&Wn)[4], int (&rc_)[NI], int (&rn)[NI]) {
 #if PCC_CONV_STAMP
     unsigned long long tq[8];
-#define PCCUP_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tq[i])::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define UP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tq[i])::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
-#define PCCUP_T(i) do { } while (0)
+#define UP_STAMP(i) do { } while (0)
 #endif
-    PCCUP_T(0);
+    UP_STAMP(0);
     f32x4 lo0, hi0, lo1, hi1;
     const float wl[8] = {Wc[0].x, Wc[0].y, Wc[0].z, Wc[0].w, Wc[1].x, Wc[1].y, Wc[1].z, Wc[1].w};
     const float wh[8] = {Wc[2].x, Wc[2].y, Wc[2].z, Wc[2].w, Wc[3].x, Wc[3].y, Wc[3].z, Wc[3].w};
@@ -375,40 +329,22 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
         g1 = h1;
       }
     }
-    PCCUP_T(6);
+    UP_STAMP(6);
     // item 0 is unconditional (pad slots into the sink row when the offset has no row).  The step's bookkeeping sits in
     // front of its MFMAs as ONE group of vector instructions, behind the request for the tiles (their LDS round trip runs
     // under it): a vector instruction between two MFMAs costs a lone wave 16 cycles, in a group 4 (tools/micro/issue.hip),
     // and f32 MFMAs share the vector ALU — whatever the partner wave does, this time is not hidden.  The records arrive
     // under the first four MFMA pairs; they are resolved and the first gather of the next offset issued in the middle.
-    PCCUP_FILL_AT(1);
     tile_read(rc_[0], lo0, hi0);
     tile_read(rc_[1], lo1, hi1);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef PCCUP_SUB_COMPACT   // timing subtractions (wrong results): pieces of the bookkeeping left out
-    const int cnt_next = cnt_cur;
-#else
     const int cnt_next = compact();   // offset j + 1
-#endif
-#ifndef PCCUP_SUB_REQ
     request_nb();                     // book entries of offset j + 2
     request_lut(j + 3);
-#endif
-#ifdef PCCUP_SUB_W
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Wn[i] = Wc[i];
-#else
     load_wj(Wn, j + 1);
-#endif
-#ifdef PCCUP_SUB_COMPACT
-#pragma unroll
-    for (int g = 0; g < NI; ++g) rn[g] = rc_[g];
-#else
     PCC16_SYNC();
     read_records(rn);
-#endif
     __builtin_amdgcn_sched_barrier(0);
-    PCCUP_FILL_AT(2);
     float xv0[8];
     shape(G[0][0], G[0][1], xv0);
 #pragma unroll
@@ -417,9 +353,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifndef PCCUP_SUB_COMPACT
     resolve(rn);
-#endif
     gather(0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -427,16 +361,15 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
       lo0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv0[s], lo0, 0, 0, 0);
       hi0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv0[s], hi0, 0, 0, 0);
     }
-    if (!PCCUP_LIVE(1)) tile_write(rc_[0], lo0, hi0);
-    PCCUP_T(5);   // item 0 with the bookkeeping
+    if (!UP_LIVE(1)) tile_write(rc_[0], lo0, hi0);
+    UP_STAMP(5);   // item 0 with the bookkeeping
     // Item g >= 1: [write-back of item g-1 behind the first MFMA pair, tile of item g+1 requested] chains of item g; the
     // last item of the step writes itself back.  The gathers of the next offset's four items are issued whether or not
     // the item exists (conv16.h: exact vmcnt counts).  (Four straight-line tails selected by the number of items instead
     // of a branch around every item were built: 5 % slower.)
-#define PCCUP_ITEM(g, LO, HI, PLO, PHI)                                                                \
-    if (PCCUP_LIVE(g)) {                                                                               \
-      const bool more = (g) + 1 < NI && PCCUP_LIVE((g) + 1);                                           \
-      PCCUP_FILL_AT(3);                                                                                \
+#define UP_ITEM(g, LO, HI, PLO, PHI)                                                                \
+    if (UP_LIVE(g)) {                                                                               \
+      const bool more = (g) + 1 < NI && UP_LIVE((g) + 1);                                              \
       float xv[8];                                                                                     \
       shape(G[g][0], G[g][1], xv);                                                                     \
       LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0], xv[0], LO, 0, 0, 0);                            \
@@ -447,14 +380,14 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
         LO = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s], xv[s], LO, 0, 0, 0);                          \
         HI = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[s], xv[s], HI, 0, 0, 0);                          \
       }                                                                                                \
-      if (!more) { PCCUP_FILL_AT(4); tile_write(rc_[g], LO, HI); }                                     \
+      if (!more) tile_write(rc_[g], LO, HI);                                                           \
     }                                                                                                  \
-    gather(g); PCCUP_FILL_AT(5)
-    PCCUP_ITEM(1, lo1, hi1, lo0, hi0);
-    PCCUP_ITEM(2, lo0, hi0, lo1, hi1);
-    PCCUP_ITEM(3, lo1, hi1, lo0, hi0);
-#undef PCCUP_ITEM
-    PCCUP_T(1);
+    gather(g)
+    UP_ITEM(1, lo1, hi1, lo0, hi0);
+    UP_ITEM(2, lo0, hi0, lo1, hi1);
+    UP_ITEM(3, lo1, hi1, lo0, hi0);
+#undef UP_ITEM
+    UP_STAMP(1);
 #if PCC_CONV_STAMP
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     st_sum[3] += tq[0] - st_last;   // loop back
@@ -467,9 +400,6 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     cnt_cur = cnt_next;
   };
 
-#ifdef PCCUP_PRIO_IRR
-  __builtin_amdgcn_s_setprio(PCCUP_PRIO_IRR);
-#endif
   // prologue of the remainder: offset 0 compacted and gathered, offset 1 requested
   PCC16_SYNC();
   request_lut(0);
@@ -484,21 +414,12 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   resolve(ra0);
 #pragma unroll
   for (int g = 0; g < NI; ++g) gather(g);
-#ifndef PCCUP_NO_IRR
   for (int j = 0; j < NJ; j += 2) {
     step(j, W0, W1, ra0, ra1);
     step(j + 1, W1, W0, ra1, ra0);
   }
-#endif
   PCC16_SYNC();
-#ifdef PCCUP_FILL_LOC
-  if (in_bytes == 12345u) acc_lds[lane] = fill_l[0] + fill_h[0];
-#endif
 
-#ifdef PCCUP_NO_EPI   // timing ablation: one word per lane instead of the epilogue
-  head_out[row0 + lane] = acc_lds[acc_at(0, lane, q)];
-  return;
-#endif
   // ---- epilogue: the window's rows are contiguous in `out` (nullptr with the colour head: the last stage of g_s).  Vector
   // instructions are what the epilogue costs (they share the ALU with the partner wave's MFMAs): one v_max per element
   // (no canonicalising copy in front of it), LDS and store addresses as immediates off one register, rows past the end
