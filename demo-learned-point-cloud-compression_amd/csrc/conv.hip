@@ -759,8 +759,9 @@ static void launch_up(hipStream_t st, const float* d_in, int64_t n_parents, cons
   const int64_t n_out = 8 * n_parents;
   if (n_out < ((int64_t)1 << 25) && pitch < ((int64_t)1 << 24) && !force_wide_rows() && !force_up_legacy()) {
     const dim3 up_grid((nblk(n_parents, 16) + 7) / 8 * 8);
+    static const int order = getenv("PCC_UP_ORDER") ? atoi(getenv("PCC_UP_ORDER")) : 0;   // EXPERIMENT (round 4)
     hipLaunchKernelGGL((k_gconv_up<PERM>), up_grid, dim3(64), 0, st, d_in, d_nbr_parent, pitch,
-                       n_parents, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, (uint32_t)(n_out * 128));
+                       n_parents, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, (uint32_t)(n_out * 128), order);
   } else {
     launch16<true, true, PERM, 32>(st, d_in, n_out, d_nbr_parent, 27, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
   }

@@ -82,3 +82,18 @@ def test_driver_line_carries_every_config():
         assert c["encode_ms"] > 0 and c["decode_ms"] > 0 and c["frames_per_s"] > 0 and c["bpp"], name
     assert all(cfg[k]["equals_oracle"] is True for k in ("C1", "C3", "C4", "zed_gop5"))
     assert cfg["C3"]["blob_version"] == 2 and cfg["C5_one_gpu"]["frames"] == 8 and cfg["zed_gop5"]["frames"] == 5
+
+
+@pytest.mark.gpu
+def test_rccl_leg_with_a_world_of_one():
+    """the tiled (N > 1) workload and its exchange over the nccl (= RCCL) backend with ONE rank on the box's one GPU
+    (PCC_BENCH_TILED=1): process-group set-up with a device id, the variable-length all-gather of device tensors, the
+    barriers and the max-over-ranks reduction of the N > 1 path run for real — RCCL refuses two ranks on one device, so a
+    world of one is the most of that leg a one-GPU box can execute.  The line says what it was: n_gpus 1, backend nccl."""
+    r = _run(["--gpus", "1", "--points", "60000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-psnr"],
+             {"PCC_BENCH_TILED": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == line["ranks_seen"] == 1 and line["backend"].startswith("nccl")
+    assert "configs[4]" in line["config"]["workload"] and line["config"]["frames_per_step_per_gpu"] == 2
+    assert len(line["ms_per_step_per_rank"]) == 1 and line["value"] > 0
