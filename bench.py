@@ -268,6 +268,8 @@ def main():
     # PCC_BENCH_TILED=1: the tiled (N > 1) workload and its RCCL exchange with a world of one rank — rehearses that
     # leg on a one-GPU box; never the headline
     tiled_mode = world > 1 or os.environ.get("PCC_BENCH_TILED") == "1"
+    if tiled_mode and world == 1:
+        os.environ["PCC_TILED_FORCE_COLLECTIVE"] = "1"    # the world of one still goes through the two collectives
     dist = None
     if tiled_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
