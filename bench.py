@@ -431,6 +431,24 @@ def main():
                             "lasts as long as ONE chunk (latency of a dependent 64-bit state update and a binary search "
                             "in LDS per step), far from the HBM roof by construction; what it buys is the removal of the "
                             "serial host coder and of the symbols' PCIe round trip"}
+    # the reference's container + seek-point trailer (pcc_codec_set_seek_points): everything the reference's reader reads
+    # is unchanged — it stops at the last frame record, in front of the trailer — and this library's decoder decodes the
+    # y string in pieces on host threads.  Informational like value_gpu_rans; `value` stays the plain container.
+    seek = None
+    if not tiled_mode:
+        pieces = int(os.environ.get("PCC_BENCH_SEEK_POINTS", "16"))
+        enc_sk = pkg.CompressionPipeline(SETTINGS, device=local, slots=1, seek_points=pieces)
+        step(True, enc_sk)
+        elapsed_sk, enc_ms_sk, dec_ms_sk, (out_sk, side_sk, rec_sk, dside_sk, _) = timed(host=True, enc=enc_sk)
+        same = all(np.array_equal(a["points"], b["points"]) and np.array_equal(a["colors"], b["colors"]) for a, b in zip(rec_sk, rec))
+        prefix = all(out_sk[q][:len(out[q])] == out[q] for q in range(1, q_dec + 1))
+        assert same and prefix, "seek-point containers: not the plain container + trailer, or another reconstruction"
+        seek = {"value": args.steps / elapsed_sk, "ms_per_step": 1e3 * elapsed_sk / args.steps, "encode_ms": enc_ms_sk,
+                "decode_ms": dec_ms_sk, "pieces": pieces, "trailer_bytes": [len(out_sk[q]) - len(out[q]) for q in range(1, q_dec + 1)],
+                "bpp": [float(b) for b in side_sk["gop_info"]["bpp"]], "container_is_version0_plus_trailer": bool(prefix),
+                "reconstruction_equals_version0": bool(same),
+                "decode_stages_ms": {k: round(1e3 * v, 3) for k, v in dside_sk["time_measurements"].items()}}
+        del enc_sk
     table = [kv for kv in table if layer_all and kv[0] == (dom_op, dom_dims)]
     if rank == 0:
         log("per-op device time of the last warm-up step (HIP events around every C-ABI call):")
@@ -621,7 +639,10 @@ def main():
                                       "the timed region), the reference's container (version 0: y / z strings single "
                                       "rANS streams coded on the host); value_hbm_resident = frame already in HBM, "
                                       "reconstruction left in HBM; value_gpu_rans = operator contract with the flagged "
-                                      "version-1 container (strings coded by the GPU's interleaved rANS)"},
+                                      "version-1 container (strings coded by the GPU's interleaved rANS); "
+                                      "value_seek_points = operator contract with the reference's container + a trailer "
+                                      "behind its last frame record (invisible to the reference's reader) from which "
+                                      "this decoder decodes the y string on 16 host threads"},
             "encode_ms": enc_ms, "decode_ms": dec_ms,
             "value_hbm_resident": frames_total / elapsed_hbm,
             "ms_per_step_hbm_resident": 1e3 * elapsed_hbm / args.steps,
@@ -629,6 +650,8 @@ def main():
             "bpp": [float(b) for b in side["gop_info"]["bpp"]],
             "value_gpu_rans": gpu_rans["value"] if gpu_rans else None,
             "gpu_rans": gpu_rans,
+            "value_seek_points": seek["value"] if seek else None,
+            "seek_points": seek,
             "d1_psnr": quality["hip"]["d1_psnr"] if quality else None,
             "y_psnr": quality["hip"]["y_psnr"] if quality else None,
             "d1_psnr_oracle": quality["oracle"]["d1_psnr"] if quality and "oracle" in quality else None,

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "pcc_codec_destroy": (None, [vp]),
     "pcc_codec_ctx": (vp, [vp]),
     "pcc_codec_set_container_version": (i32, [vp, i32]),
+    "pcc_codec_set_seek_points": (i32, [vp, i32]),
     "pcc_encode_gop": (i32, [vp, vp, vp, i64, i32, C.POINTER(C.c_double), i32, C.POINTER(PccBuf), pi64,
                              C.POINTER(C.c_double)]),
     "pcc_encode_gop_frames": (i32, [vp, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p), i32, pi64, i32,
@@ -120,6 +121,8 @@ PROTOTYPES = {
     "pcc_gaussian_indexes8": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
     "pcc_rans_encode_multi16": (i32, [vp, vp, i64, i32, vp, i32, vp, vp, i32, vp, i64, pi64]),
     "pcc_rans_decode8": (i32, [vp, i64, vp, i64, vp, i32, vp, vp, i32, vp]),
+    "pcc_rans_encode_seek": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i64, pi64, vp, i32, vp, vp]),
+    "pcc_rans_decode_range": (i32, [vp, i64, vp, i64, vp, i32, vp, vp, i32, vp, i64, i64, C.c_uint64, i64, vp, pi64]),
     "pcc_gaussian_dequant": (i32, [vp, vp, vp, i64, i32, vp, f32, f32, f32, vp]),
     "pcc_rans_encode": (i32, [vp, vp, i64, vp, i32, vp, vp, i32, vp, i64, pi64]),
     "pcc_rans_decode": (i32, [vp, i64, vp, i64, vp, i32, vp, vp, i32, vp]),

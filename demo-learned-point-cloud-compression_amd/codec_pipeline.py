@@ -55,7 +55,7 @@ def _to_dev_as_is(a, keep, other, device):
 
 class CompressionPipeline:
     def __init__(self, settings, device=0, slots=3, stage_sync=None, engine=None, container_version=None,
-                 base_path=None):
+                 base_path=None, seek_points=None):
         self.device = torch.device("cuda", device)
         # 0 (default): the reference's container, y / z strings coded by the host coder in CompressAI's format;
         # 1 (or PCC_CONTAINER_VERSION=1): flagged extension, y / z strings in the GPU coder's interleaved form
@@ -67,6 +67,13 @@ class CompressionPipeline:
         self.engine = engine or os.environ.get("PCC_ENGINE", "native")
         if self.engine not in ("native", "ops"):
             raise ValueError(f"engine must be 'native' or 'ops', got {self.engine!r}")
+        # seek points (0 = none, the default; or PCC_SEEK_POINTS): the reference's container with a trailer BEHIND its last
+        # frame record that holds the y coder's state at that many cuts of the symbol array (include/pcc.h,
+        # pcc_codec_set_seek_points).  The reference's reader stops at the last frame record and never sees it; this
+        # package's decoder decodes the pieces on as many host threads.  Native engine, container version 0.
+        self.seek_points = int(os.environ.get("PCC_SEEK_POINTS", "0")) if seek_points is None else int(seek_points)
+        if self.seek_points and (self.engine != "native" or self.container_version != 0):
+            raise ValueError("seek_points needs engine='native' and container_version=0")
         # stage_sync=True: synchronise the stream at the end of every stage so that enc_time_measurements
         # holds per-stage wall times; False (default, PCC_STAGE_SYNC=1 overrides): stages are enqueued
         # back to back like the reference's asynchronous torch ops and only data hand-overs wait
@@ -78,7 +85,7 @@ class CompressionPipeline:
         self.compression_model = self.load_model(base_path)
         self._slots = queue.Queue()
         if self.engine == "native":
-            self.codecs = [NativeCodec(self.compression_model.tensors, device, self.container_version)
+            self.codecs = [NativeCodec(self.compression_model.tensors, device, self.container_version, self.seek_points)
                            for _ in range(slots)]
             self.runtimes = [c.rt for c in self.codecs]
             for c in self.codecs:

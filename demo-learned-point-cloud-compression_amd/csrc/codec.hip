@@ -250,6 +250,11 @@ struct pcc_codec {
   // strings single rANS streams coded on the host; 1 = flagged extension, y and z strings wave-interleaved streams
   // coded on the GPU (rans_gpu.hip).  The decoder reads the version from the container.
   int container_version = 0;
+  // seek points of the host-coded y strings (pcc_codec_set_seek_points): > 1 = version-0 containers get a "PCSK" trailer
+  // behind their last frame record — the state and stream position of the y coder at that many cuts of the symbol array.
+  // The reference's reader stops at the last frame record (codec_parallel.py:200-213) and never sees it; this library's
+  // decoder decodes the pieces between the points on as many host threads.
+  int seek_points = 0;
   pcc_rans_dev *gc_dev = nullptr, *eb_dev = nullptr;  // the two CDF sets in HBM for the GPU coder
   PccWorkers workers;                  // the Q coder threads of the encoder
   DevPool pool;
@@ -855,6 +860,24 @@ extern "C" pcc_codec* pcc_codec_create(const void* h_ckpt, size_t n, int device,
   return cd;
 }
 
+extern "C" int pcc_codec_set_seek_points(pcc_codec* cd, int pieces) {
+  PCC_REQUIRE(cd, PCC_E_ARG, "pcc_codec_set_seek_points: null codec");
+  PCC_REQUIRE(pieces == 0 || (pieces >= 2 && pieces <= 64), PCC_E_ARG, "pcc_codec_set_seek_points: %d pieces (0, or 2 .. 64)", pieces);
+  cd->seek_points = pieces;
+  return PCC_OK;
+}
+
+// the seek points of an n-symbol stream cut into `pieces` (oracle/codec_ref.py seek_indexes): multiples of 64 near
+// k n / pieces, ascending, inside (0, n); none for streams under 65536 symbols
+static void seek_indexes(int64_t n, int pieces, std::vector<int64_t>* out) {
+  out->clear();
+  if (pieces < 2 || n < 65536) return;
+  for (int k = 1; k < pieces; ++k) {
+    const int64_t i = (n * k / pieces) & ~(int64_t)63;
+    if (i > 0 && i < n && (out->empty() || i > out->back())) out->push_back(i);
+  }
+}
+
 extern "C" int pcc_codec_set_container_version(pcc_codec* cd, int version) {
   PCC_REQUIRE(cd, PCC_E_ARG, "pcc_codec_set_container_version: null codec");
   PCC_REQUIRE(version == 0 || version == 1, PCC_E_ARG, "pcc_codec_set_container_version: version %d (0 or 1)", version);
@@ -1364,6 +1387,9 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   t0 = now_s();
   std::vector<std::vector<uint8_t>> y_strings((size_t)n_q);  // only the int16-overflow path below fills these
   std::vector<uint8_t> head_done((size_t)n_q, 0);
+  std::vector<int64_t> seek_idx;                     // seek points of the y strings (cd->seek_points; version 0 only)
+  std::vector<std::vector<uint64_t>> seek_state;     // [quality][point]
+  std::vector<std::vector<int64_t>> seek_word;
   if (v1) {
     // Container version 1: symbols and indexes stay in HBM, the Q y streams and the z stream are coded by the GPU's
     // interleaved coder behind the quantiser, and only the finished streams cross PCIe.  The geometry slots (device
@@ -1473,6 +1499,9 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     int64_t cap = 2 * per + 4096;
     std::vector<int> rcq((size_t)n_q, PCC_OK);
     std::vector<std::string> errq((size_t)n_q);
+    seek_indexes(per, v1 ? 0 : cd->seek_points, &seek_idx);
+    seek_state.assign((size_t)n_q, std::vector<uint64_t>(seek_idx.size() + 1, 0));
+    seek_word.assign((size_t)n_q, std::vector<int64_t>(seek_idx.size() + 1, 0));
     int side_rc = PCC_OK;
     const int64_t nz_for_header = nz;
     auto code_quality = [&](int q) {
@@ -1495,10 +1524,11 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       std::unique_ptr<uint8_t[]> ybuf;  // not cleared: a std::vector of the worst-case size would memset 1.7 MB first
       for (int attempt = 0; attempt < 2; ++attempt) {
         ybuf.reset(new uint8_t[(size_t)capq]);
-        rcq[q] = pcc_rans_encode16_gated((const int16_t*)cd->pin_ysym.p + (size_t)q * per,
-                                         cd->pin_yidx.p + (size_t)q * per, per, gc_cdf->i32(), (int)gc_cdf->dims[1],
-                                         gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], ybuf.get(), capq, &got,
-                                         &gate, cd->gc_tables);
+        PccRansSeek seek{(int)seek_idx.size(), seek_idx.data(), seek_state[q].data(), seek_word[q].data()};
+        rcq[q] = pcc_rans_encode16_seek((const int16_t*)cd->pin_ysym.p + (size_t)q * per,
+                                        cd->pin_yidx.p + (size_t)q * per, per, gc_cdf->i32(), (int)gc_cdf->dims[1],
+                                        gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], ybuf.get(), capq, &got,
+                                        &gate, cd->gc_tables, seek_idx.empty() ? nullptr : &seek);
         if (rcq[q] != PCC_E_NOMEM) break;
         capq = 48 * per + 4096;
       }
@@ -1592,6 +1622,17 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       for (int s = 0; s < 3; ++s) put_be32(o, (int32_t)(*kk[s])[f]);
       o.insert(o.end(), blobs[f].begin(), blobs[f].end());
     }
+    if (head_done[q] && !seek_idx.empty()) {   // "PCSK" | count | count x (index | state | words consumed), big-endian
+      const char magic[4] = {'P', 'C', 'S', 'K'};
+      o.insert(o.end(), magic, magic + 4);
+      put_be32(o, (int32_t)seek_idx.size());
+      for (size_t k = 0; k < seek_idx.size(); ++k) {
+        put_be32(o, (int32_t)seek_idx[k]);
+        put_be32(o, (int32_t)(uint32_t)(seek_state[q][k] >> 32));
+        put_be32(o, (int32_t)(uint32_t)seek_state[q][k]);
+        put_be32(o, (int32_t)seek_word[q][k]);
+      }
+    }
     h_out[q].data = o.data();
     h_out[q].len = (int64_t)o.size();
   }
@@ -1656,6 +1697,28 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     for (int s = 0; s < 3; ++s) ks[s].push_back(r.be32());
     slots[f] = {r.bytes(pl), pl};
     PCC_REQUIRE(!r.bad, PCC_E_STREAM, "pcc_decode_gop: truncated container");
+  }
+  // Behind the last frame record the reference's reader stops (codec_parallel.py:200-213).  This library's encoder may
+  // have left the seek points of the y string there ("PCSK" | count | count x (index | state | words consumed)); they
+  // are a hint — every piece decoded from one is checked against the next point, and a trailer that does not parse or
+  // does not check out is ignored (the string is then decoded serially, as the reference decodes it)
+  std::vector<int64_t> sk_idx, sk_word;
+  std::vector<uint64_t> sk_state;
+  if (!v1 && len - r.pos >= 8 && memcmp(h_in + r.pos, "PCSK", 4) == 0) {
+    Reader t{h_in + r.pos + 4, len - r.pos - 4};
+    const int32_t cnt = t.be32();
+    bool ok = cnt >= 1 && cnt <= 63 && (int64_t)cnt * 16 <= t.len - t.pos;
+    for (int k = 0; ok && k < cnt; ++k) {
+      const int64_t i = t.be32();
+      const uint64_t hi = (uint32_t)t.be32(), lo = (uint32_t)t.be32();
+      const int64_t w = t.be32();
+      ok = !t.bad && i > (sk_idx.empty() ? 0 : sk_idx.back()) && i < (int64_t)ny_hdr * cy && w >= 2 && w * 4 <= ylen &&
+           ((hi << 32) | lo) >= ((uint64_t)1 << 31);
+      sk_idx.push_back(i);
+      sk_state.push_back((hi << 32) | lo);
+      sk_word.push_back(w);
+    }
+    if (!ok) sk_idx.clear();
   }
   ts[0] = now_s() - t0;
 
@@ -1913,6 +1976,36 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
         PCC_TRY(up_of(cd, ycs, &c0));
         PCC_TRY(nbr27_of(cd, pcc_conv_up_fused() ? ycs : c0, &nbr0));
       }
+      // seek points: the pieces between them on host threads, each checked against the point behind it
+      bool decoded = false;
+      if (!sk_idx.empty() && cd->gc_tables) {
+        const int pieces = (int)sk_idx.size() + 1;
+        std::vector<int> prc((size_t)pieces, PCC_OK);
+        std::vector<uint64_t> end_x((size_t)pieces, 0);
+        std::vector<int64_t> end_w((size_t)pieces, 0);
+        auto piece = [&](int k) {
+          const int64_t lo = k == 0 ? 0 : sk_idx[k - 1], hi = k == pieces - 1 ? tot : sk_idx[k];
+          prc[k] = pcc_rans_decode8_range(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1], gc_len->i32(),
+                                          gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p, cd->gc_tables, lo, hi,
+                                          k == 0 ? 0 : sk_state[k - 1], k == 0 ? 0 : sk_word[k - 1], &end_x[k], &end_w[k]);
+        };
+        {
+          struct WaitPieces {
+            PccWorkers& w;
+            ~WaitPieces() { w.wait_all(); }
+          } wait_pieces{cd->workers};
+          cd->workers.ensure(pieces - 1);
+          for (int k = 1; k < pieces; ++k) cd->workers.run(k - 1, [&piece, k]() { piece(k); });
+          piece(0);
+        }
+        decoded = true;
+        for (int k = 0; k < pieces; ++k) {
+          decoded &= prc[k] == PCC_OK;
+          if (k + 1 < pieces) decoded &= end_x[k] == sk_state[k] && end_w[k] == sk_word[k];
+        }
+        if (decoded)
+          PCC_HIP(hipMemcpyAsync(sym_d, cd->pin_dec.p, (size_t)tot * 4, hipMemcpyHostToDevice, st));
+      }
       // the decoded symbols go back to the device in pieces while the host is still decoding the next piece
       const int n_chunks = tot >= (1 << 16) ? 4 : 1;
       std::vector<int64_t> bound((size_t)n_chunks);
@@ -1933,9 +2026,10 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
                            g->failed = true;
                        },
                        &up};
-      PCC_TRY(pcc_rans_decode8_gated(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1],
-                                     gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p,
-                                     &gate, cd->gc_tables));
+      if (!decoded)
+        PCC_TRY(pcc_rans_decode8_gated(ystr, ylen, cd->pin_yidx.p, tot, gc_cdf->i32(), (int)gc_cdf->dims[1],
+                                       gc_len->i32(), gc_off->i32(), (int)gc_cdf->dims[0], (int32_t*)cd->pin_dec.p,
+                                       &gate, cd->gc_tables));
       PCC_REQUIRE(!up.failed, PCC_E_HIP, "pcc_decode_gop: hipMemcpyAsync of decoded symbols failed");
       PCC_TRY(pcc_gaussian_dequant(ctx, sym_d, params, ny, cy, scale_d, tab->f32()[0], ab->f32()[0], ab->f32()[1], rows));
     }

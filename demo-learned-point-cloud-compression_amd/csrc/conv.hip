@@ -855,6 +855,13 @@ extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_i
                                     const float* d_head_w, const float* d_head_b, float* d_head_out) {
   PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_sparse_conv_head: null ctx");
   PCC_REQUIRE(d_head_w && d_head_b && d_head_out, PCC_E_ARG, "pcc_sparse_conv_head: null head buffers");
+  // "siblings first" is DEFINED on row indexes: a neighbour belongs to the first pass when (input row >> 3) ==
+  // (output row >> 3) — "same parent" on a generative level (rows in aligned blocks of the 8 children of a parent), and
+  // simply "same aligned block of 8 rows" on any other set, for which the order is as deterministic and is what
+  // oracle/pcc_oracle.c computes too (include/pcc.h).  It needs input and output rows to be the same set:
+  PCC_REQUIRE(n_in == n_out, PCC_E_ARG,
+              "pcc_sparse_conv_head: the siblings-first order compares input and output row indexes: n_in %lld != n_out %lld",
+              (long long)n_in, (long long)n_out);
   if (n_out > 0 && cout == 32 && d_in && d_nbr && d_w && d_bias && d_out && nbr_pitch >= n_out && n_in > 0 &&
       conv16_shape(d_in, d_out, k_vol, cin, cout)) {
     const float* wsw;
@@ -945,7 +952,8 @@ extern "C" const char* pcc_conv_kernel_name(int op, int k_vol, int cin, int cout
   if (force_scalar()) return op == 2 ? "k_convT_scalar" : "k_gconv_scalar";
   if (op == 2 && cin == 32 && cout == 32 && !convT_legacy()) return "k_convT16";
   if (op == 2) return convT_widths(cin, cout) ? "k_convT_mfma" : "k_convT_scalar";
-  const bool sib = op == 1;
+  const bool sib = op == 1;   // pcc_sparse_conv_head: conv + 1-channel head, siblings first
+  if (sib && cin == 32 && cout == 32 && (k_vol == 27 || k_vol == 8)) return "k_gconv16";   // its fused HEAD form
   if (!sib && cin == 32 && (cout == 32 || cout == 64) && (k_vol == 27 || k_vol == 8)) return "k_gconv16";
   if (convgen_widths(k_vol, cin, cout)) return "k_gconv_gen";
   if (!sib && cin == 4 && cout % 16 == 0 && cout <= 128) return "k_gconv_first";

@@ -26,6 +26,24 @@ int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t 
                             int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
                             uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate,
                             const PccRansTables* tables);
+// Seek points of a host-coded stream (codec.hip's "PCSK" trailer): index[k] ascending symbol positions, filled by the
+// encoder with the coder's state and the number of 32-bit words a decoder has consumed when symbol index[k] is next.
+// A decoder that holds them decodes the pieces between the points on as many threads, each piece checked against the
+// point behind it (pcc_rans_decode8_range returns where it ended).
+struct PccRansSeek {
+  int n;
+  const int64_t* index;
+  uint64_t* state;
+  int64_t* word;
+};
+int pcc_rans_encode16_seek(const int16_t* h_sym, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                           int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                           uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate,
+                           const PccRansTables* tables, PccRansSeek* seek);
+int pcc_rans_decode8_range(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                           int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, int32_t* h_sym,
+                           const PccRansTables* tables, int64_t i_lo, int64_t i_hi, uint64_t state_in, int64_t word_in,
+                           uint64_t* state_out, int64_t* word_out);
 int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
                            int32_t* h_sym, const PccRansGate* gate, const PccRansTables* tables);

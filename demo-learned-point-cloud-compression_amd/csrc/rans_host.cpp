@@ -130,7 +130,7 @@ template <typename SymT, typename IdxT>
 int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cdfs, int pitch,
                   const int32_t* sizes, const int32_t* offsets, int n_cdf, uint8_t* out, int64_t cap,
                   int64_t* len, char* err, size_t errlen, const PccRansGate* gate = nullptr,
-                  const EncTables* pre = nullptr) {
+                  const EncTables* pre = nullptr, PccRansSeek* seek = nullptr) {
   // worst case per symbol: 1 main step + (1..2 unary) + 8 raw nibbles; each step emits at most
   // one 32-bit word, and in-range symbols (the common case) emit 16 bits on average.  Size the
   // staging buffer for the common case and grow on demand.
@@ -153,9 +153,17 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
     e.ptr = buf.get() + buf_words;
     e.overflow = false;
     const int n_chunks = gate ? gate->n_chunks : 1;
+    // seek points (PccRansSeek): the coder's state and the words it has emitted, noted when it has coded every symbol
+    // from index[k] on — where a decoder stands when it has decoded the symbols in front of index[k].  The coder walks
+    // the array backwards: points are met from the last to the first, between two symbols (never inside an escape).
+    int sk = seek ? seek->n - 1 : -1;
+    while (sk >= 0 && seek->index[sk] >= n) --sk;   // (a point at or behind the end is never met: left at state 0)
     for (int ch = 0; ch < n_chunks; ++ch) {
-    const int64_t i_hi = (ch == 0 ? n : gate->bound[ch - 1]) - 1, i_lo = gate ? gate->bound[ch] : 0;
+    const int64_t c_hi = (ch == 0 ? n : gate->bound[ch - 1]) - 1, c_lo = gate ? gate->bound[ch] : 0;
     if (gate) gate->fn(gate->user, ch);  // chunk ch has arrived (returns at once on a second attempt)
+    for (int64_t i_hi = c_hi; i_hi >= c_lo;) {
+    // the piece of this chunk down to the next seek point (or to the chunk's start)
+    const int64_t i_lo = (sk >= 0 && seek->index[sk] > c_lo) ? std::min<int64_t>(seek->index[sk], i_hi + 1) : c_lo;
     for (int64_t i = i_hi; i >= i_lo; --i) {
       const int32_t ci = (int32_t)idx[i];
       if ((uint32_t)ci >= (uint32_t)n_cdf) {
@@ -184,6 +192,13 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
       }
       e.put(es);
     }
+    while (sk >= 0 && seek->index[sk] >= i_lo && seek->index[sk] > 0) {   // the symbols from index[sk] on are coded
+      seek->state[sk] = e.x;
+      seek->word[sk] = (int64_t)((buf.get() + buf_words) - e.ptr);   // words emitted so far (turned into an offset below)
+      --sk;
+    }
+    i_hi = i_lo - 1;
+    }
     }
     // flush: two words, low then high
     e.emit((uint32_t)(e.x >> 32));
@@ -201,6 +216,15 @@ int encode_stream(const SymT* sym, const IdxT* idx, int64_t n, const int32_t* cd
     }
     memcpy(out, e.ptr, (size_t)nbytes);  // little-endian u32 words, as CompressAI returns them
     *len = nbytes;
+    if (seek) {
+      // the decoder reads the stream forwards: the two flush words, then the coder's words last to first.  With m words
+      // emitted when point k was met and M in all, the decoder has consumed 2 + (M - m) words when it gets there
+      const int64_t total = nbytes / 4;   // M + 2
+      for (int k = 0; k < seek->n; ++k) {
+        if (seek->index[k] <= 0 || seek->index[k] >= n) { seek->state[k] = 0; seek->word[k] = 0; continue; }
+        seek->word[k] = total - seek->word[k];
+      }
+    }
     return PCC_OK;
   }
   snprintf(err, errlen, "rans encode: internal buffer overflow");
@@ -292,21 +316,34 @@ int build_dec_tables(const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_size
   return PCC_OK;
 }
 
+// where a decoder stands between two symbols: its state and the 32-bit words of the stream it has consumed
+struct DecPos {
+  uint64_t x;
+  int64_t word;
+};
 template <typename IdxT>
 int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n, const int32_t* h_cdfs,
                   int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, int32_t* h_sym,
-                  const char* who, const PccRansGate* gate = nullptr, const DecTables* pre = nullptr) {
+                  const char* who, const PccRansGate* gate = nullptr, const DecTables* pre = nullptr,
+                  int64_t r_lo = 0, int64_t r_hi = -1, const DecPos* from = nullptr, DecPos* to = nullptr) {
   if (!h_in || len < 8 || n < 0 || (n > 0 && (!h_idx || !h_sym)) || !h_cdfs || !h_sizes || !h_offsets ||
       cdf_pitch < 2 || n_cdf < 1) {
     pcc_set_error("%s: bad argument (len=%lld)", who, (long long)len);
     return len < 8 ? PCC_E_STREAM : PCC_E_ARG;
   }
+  // a range [r_lo, r_hi) of the symbols from a given position (seek points): no chunk gate, every CDF table prebuilt
+  const bool ranged = from != nullptr;
+  if (r_hi < 0) r_hi = n;
+  if (ranged && (gate || r_lo < 0 || r_lo > r_hi || r_hi > n || from->word < 2 || from->word * 4 > len)) {
+    pcc_set_error("%s: bad range", who);
+    return PCC_E_ARG;
+  }
   // ---- indexes are validated up front (keeps the check out of the serial loop)
   {
     uint32_t worst = 0;
-    for (int64_t i = 0; i < n; ++i) worst = std::max(worst, (uint32_t)(int32_t)h_idx[i]);
-    if (n > 0 && worst >= (uint32_t)n_cdf) {
-      for (int64_t i = 0; i < n; ++i)
+    for (int64_t i = r_lo; i < r_hi; ++i) worst = std::max(worst, (uint32_t)(int32_t)h_idx[i]);
+    if (r_hi > r_lo && worst >= (uint32_t)n_cdf) {
+      for (int64_t i = r_lo; i < r_hi; ++i)
         if ((uint32_t)(int32_t)h_idx[i] >= (uint32_t)n_cdf) {
           pcc_set_error("%s: index %d out of range at %lld", who, (int32_t)h_idx[i], (long long)i);
           return PCC_E_ARG;
@@ -317,7 +354,7 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
   DecTables local;
   if (!pre) {
     std::vector<uint8_t> used((size_t)n_cdf, 0);
-    for (int64_t i = 0; i < n; ++i) used[(size_t)(int32_t)h_idx[i]] = 1;
+    for (int64_t i = r_lo; i < r_hi; ++i) used[(size_t)(int32_t)h_idx[i]] = 1;
     const int rc = build_dec_tables(h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, used.data(), &local, who);
     if (rc != PCC_OK) return rc;
     pre = &local;
@@ -333,11 +370,17 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
     return w;
   };
   bool bad = false;
-  uint64_t x = word(bad);
-  x |= (uint64_t)word(bad) << 32;
+  uint64_t x;
+  if (ranged) {
+    x = from->x;
+    p = h_in + from->word * 4;
+  } else {
+    x = word(bad);
+    x |= (uint64_t)word(bad) << 32;
+  }
   const int n_chunks = gate ? gate->n_chunks : 1;
   for (int ch = 0; ch < n_chunks; ++ch) {
-  const int64_t i_lo = ch == 0 ? 0 : gate->bound[ch - 1], i_hi = gate ? gate->bound[ch] : n;
+  const int64_t i_lo = gate ? (ch == 0 ? 0 : gate->bound[ch - 1]) : r_lo, i_hi = gate ? gate->bound[ch] : r_hi;
   for (int64_t i = i_lo; i < i_hi; ++i) {
     const DecTab& t = tabs[(size_t)(int32_t)h_idx[i]];
     const uint32_t cum = (uint32_t)(x & 0xFFFFu);
@@ -382,6 +425,10 @@ int decode_stream(const uint8_t* h_in, int64_t len, const IdxT* h_idx, int64_t n
   if (bad) {
     pcc_set_error("%s: truncated stream", who);
     return PCC_E_STREAM;
+  }
+  if (to) {
+    to->x = x;
+    to->word = (int64_t)(p - h_in) / 4;
   }
   return PCC_OK;
 }
@@ -438,6 +485,52 @@ int pcc_rans_encode16_gated(const int16_t* h_sym, const uint8_t* h_idx, int64_t 
   return rc;
 }
 
+int pcc_rans_encode16_seek(const int16_t* h_sym, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                           int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                           uint8_t* h_out, int64_t cap, int64_t* h_len, const PccRansGate* gate,
+                           const PccRansTables* tables, PccRansSeek* seek) {
+  if (!h_len || n < 0 || (n > 0 && (!h_sym || !h_idx)) || !h_cdfs || !h_sizes || !h_offsets || !h_out ||
+      cdf_pitch < 2 || n_cdf < 1 || !gate_ok(gate, n, true)) {
+    pcc_set_error("pcc_rans_encode16_seek: bad argument");
+    return PCC_E_ARG;
+  }
+  if (seek)
+    for (int k = 0; k < seek->n; ++k)
+      if (!seek->index || !seek->state || !seek->word || (k > 0 && seek->index[k] < seek->index[k - 1])) {
+        pcc_set_error("pcc_rans_encode16_seek: seek indexes must ascend");
+        return PCC_E_ARG;
+      }
+  char err[256] = {0};
+  const int rc = encode_stream(h_sym, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out, cap, h_len, err,
+                               sizeof(err), gate, tables ? &tables->enc : nullptr, seek);
+  if (rc != PCC_OK) pcc_set_error("pcc_rans_encode16_seek: %s", err);
+  return rc;
+}
+
+// symbols [i_lo, i_hi) of a stream from a seek point (state_in, word_in: 32-bit words consumed so far; i_lo == 0 with
+// word_in == 0 starts at the head of the stream); *state_out / *word_out = where the decoder stands behind symbol i_hi - 1
+int pcc_rans_decode8_range(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                           int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf, int32_t* h_sym,
+                           const PccRansTables* tables, int64_t i_lo, int64_t i_hi, uint64_t state_in, int64_t word_in,
+                           uint64_t* state_out, int64_t* word_out) {
+  if (!tables || !state_out || !word_out || !h_in || len < 8) {
+    pcc_set_error("pcc_rans_decode8_range: bad argument");
+    return PCC_E_ARG;
+  }
+  DecPos from{state_in, word_in}, to{0, 0};
+  if (i_lo == 0 && word_in == 0) {   // the head of the stream: its first two words are the state
+    uint32_t w[2];
+    memcpy(w, h_in, 8);
+    from.x = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    from.word = 2;
+  }
+  const int rc = decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
+                               "pcc_rans_decode8_range", nullptr, &tables->dec, i_lo, i_hi, &from, &to);
+  *state_out = to.x;
+  *word_out = to.word;
+  return rc;
+}
+
 int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n, const int32_t* h_cdfs,
                            int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
                            int32_t* h_sym, const PccRansGate* gate, const PccRansTables* tables) {
@@ -478,6 +571,51 @@ extern "C" int pcc_rans_decode(const uint8_t* h_in, int64_t len, const int32_t* 
                                const int32_t* h_offsets, int n_cdf, int32_t* h_sym) {
   return decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
                        "pcc_rans_decode");
+}
+
+// op-level forms of the seek points (include/pcc.h): int32 symbols / indexes, tables built per call
+extern "C" int pcc_rans_encode_seek(const int32_t* h_sym, const int32_t* h_idx, int64_t n, const int32_t* h_cdfs,
+                                    int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
+                                    uint8_t* h_out, int64_t cap, int64_t* h_len, const int64_t* h_seek_index, int n_seek,
+                                    uint64_t* h_seek_state, int64_t* h_seek_word) {
+  if (!h_len || n < 0 || (n > 0 && (!h_sym || !h_idx)) || !h_cdfs || !h_sizes || !h_offsets || !h_out || cdf_pitch < 2 ||
+      n_cdf < 1 || n_seek < 0 || (n_seek > 0 && (!h_seek_index || !h_seek_state || !h_seek_word))) {
+    pcc_set_error("pcc_rans_encode_seek: bad argument");
+    return PCC_E_ARG;
+  }
+  for (int k = 1; k < n_seek; ++k)
+    if (h_seek_index[k] < h_seek_index[k - 1]) {
+      pcc_set_error("pcc_rans_encode_seek: seek indexes must ascend");
+      return PCC_E_ARG;
+    }
+  PccRansSeek seek{n_seek, h_seek_index, h_seek_state, h_seek_word};
+  char err[256] = {0};
+  const int rc = encode_stream(h_sym, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_out, cap, h_len, err,
+                               sizeof(err), nullptr, nullptr, n_seek ? &seek : nullptr);
+  if (rc != PCC_OK) pcc_set_error("pcc_rans_encode_seek: %s", err);
+  return rc;
+}
+
+extern "C" int pcc_rans_decode_range(const uint8_t* h_in, int64_t len, const int32_t* h_idx, int64_t n,
+                                     const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes, const int32_t* h_offsets,
+                                     int n_cdf, int32_t* h_sym, int64_t i_lo, int64_t i_hi, uint64_t state_in,
+                                     int64_t word_in, uint64_t* h_state_out, int64_t* h_word_out) {
+  if (!h_state_out || !h_word_out || !h_in || len < 8) {
+    pcc_set_error("pcc_rans_decode_range: bad argument");
+    return len < 8 && h_in ? PCC_E_STREAM : PCC_E_ARG;
+  }
+  DecPos from{state_in, word_in}, to{0, 0};
+  if (i_lo == 0 && word_in == 0) {
+    uint32_t w[2];
+    memcpy(w, h_in, 8);
+    from.x = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    from.word = 2;
+  }
+  const int rc = decode_stream(h_in, len, h_idx, n, h_cdfs, cdf_pitch, h_sizes, h_offsets, n_cdf, h_sym,
+                               "pcc_rans_decode_range", nullptr, nullptr, i_lo, i_hi, &from, &to);
+  *h_state_out = to.x;
+  *h_word_out = to.word;
+  return rc;
 }
 
 extern "C" int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx, int64_t n,

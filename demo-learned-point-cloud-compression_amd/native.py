@@ -55,7 +55,7 @@ def pack_checkpoint(tensors):
 class NativeCodec:
     """one codec = weights in HBM + stream + device pool: one per in-flight call"""
 
-    def __init__(self, tensors, device=0, container_version=0):
+    def __init__(self, tensors, device=0, container_version=0, seek_points=0):
         if not torch.cuda.is_available():
             raise RuntimeError("demo-learned-point-cloud-compression_amd needs a HIP device (no CPU fallback)")
         self.lib = _abi.lib()
@@ -70,6 +70,8 @@ class NativeCodec:
         if container_version:
             check(self.lib.pcc_codec_set_container_version(self.handle, int(container_version)),
                   "pcc_codec_set_container_version")
+        if seek_points:
+            check(self.lib.pcc_codec_set_seek_points(self.handle, int(seek_points)), "pcc_codec_set_seek_points")
 
     def close(self):
         if getattr(self, "handle", None):

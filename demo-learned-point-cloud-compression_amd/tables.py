@@ -30,7 +30,9 @@ def pmf_to_quantized_cdf(pmf, precision=PRECISION):
     if not (np.all(np.isfinite(pmf)) and np.all(pmf >= 0)):
         raise ValueError("pmf_to_quantized_cdf: pmf must be finite and non-negative")
     cdf = np.zeros(pmf.shape[0] + 1, dtype=np.uint64)
-    cdf[1:] = np.floor(pmf * np.float32(1 << precision) + np.float32(0.5)).astype(np.uint64)
+    # std::round of the float32 product, half away from zero: the + 0.5 in double (exact) — in float32 the value just below
+    # 0.5 plus 0.5 rounds up to 1.0, where std::round gives 0
+    cdf[1:] = np.floor((pmf * np.float32(1 << precision)).astype(np.float64) + 0.5).astype(np.uint64)
     total = int(cdf.sum())
     if total <= 0:
         raise ValueError("pmf_to_quantized_cdf: empty pmf")

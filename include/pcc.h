@@ -420,6 +420,24 @@ int pcc_rans_decode8(const uint8_t* h_in, int64_t len, const uint8_t* h_idx,
                      const int32_t* h_sizes, const int32_t* h_offsets, int n_cdf,
                      int32_t* h_sym);
 
+/* Seek points of a host-coded stream (round 4; pcc_codec_set_seek_points puts them into a container trailer).
+ * _encode_seek: pcc_rans_encode, and for every h_seek_index[k] (ascending) inside (0, n) the coder's state and the
+ * number of 32-bit words of the stream a decoder has consumed when symbol h_seek_index[k] is the next it decodes
+ * (0 / 0 for an index outside (0, n)).  _decode_range: the symbols [i_lo, i_hi) from such a point (state_in, word_in;
+ * i_lo == 0 with word_in == 0: the head of the stream), written to h_sym[i_lo .. i_hi); *h_state_out / *h_word_out =
+ * where the decoder stands behind symbol i_hi - 1 — equal to the next point's values when stream and points agree.
+ * The pieces between seek points are independent: any number of threads may decode them at once. */
+int pcc_rans_encode_seek(const int32_t* h_sym, const int32_t* h_idx, int64_t n,
+                         const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                         const int32_t* h_offsets, int n_cdf, uint8_t* h_out, int64_t cap,
+                         int64_t* h_len, const int64_t* h_seek_index, int n_seek,
+                         uint64_t* h_seek_state, int64_t* h_seek_word);
+int pcc_rans_decode_range(const uint8_t* h_in, int64_t len, const int32_t* h_idx, int64_t n,
+                          const int32_t* h_cdfs, int cdf_pitch, const int32_t* h_sizes,
+                          const int32_t* h_offsets, int n_cdf, int32_t* h_sym, int64_t i_lo,
+                          int64_t i_hi, uint64_t state_in, int64_t word_in,
+                          uint64_t* h_state_out, int64_t* h_word_out);
+
 /* ---- range-ANS on the GPU: container version 1 (flagged extension) ------ */
 
 /* Same call sites as the host coders above (codec_pipeline.py:305-306,426-430;
@@ -582,6 +600,16 @@ pcc_ctx* pcc_codec_ctx(pcc_codec* codec); /* the codec's ctx (stream, profiler) 
 #define PCC_CONTAINER_V0 0
 #define PCC_CONTAINER_V1 1
 int pcc_codec_set_container_version(pcc_codec* codec, int version);
+/* Seek points of the host-coded y strings (round 4).  pieces > 1: a version-0 container written by this codec carries,
+ * BEHIND its last frame record, the trailer "PCSK" | int32 count | count x (int32 symbol index | uint64 coder state |
+ * int32 32-bit words consumed) — where a decoder of the y string stands at `pieces` - 1 cuts of the symbol array
+ * (multiples of 64 near k n / pieces; none for strings under 65536 symbols).  Everything in front of the trailer is
+ * the reference's container byte for byte, and the reference's reader never reaches the trailer: it reads exactly
+ * num_frames frame records (receiver/decoder/codec_parallel.py:200-213).  pcc_decode_gop* decodes the pieces between
+ * the points on as many host threads, checks every piece's end against the next point and falls back to the serial
+ * decode when a trailer does not parse or check out (a container without one is decoded serially as before).
+ * 0 (default): no trailer. */
+int pcc_codec_set_seek_points(pcc_codec* codec, int pieces);
 
 /* d_coords int32 [n,4] rows (b,x,y,z), b in [0,n_frames); d_feats float32 [n,4]
  * = (1,r,g,b) (codec_pipeline.py:258); h_q [n_q,2] = (q_g,q_a) per quality

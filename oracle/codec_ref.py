@@ -215,6 +215,41 @@ class Oracle:
         assert n >= 0
         return out[:n].tobytes()
 
+    @staticmethod
+    def seek_indexes(n, seek_points):
+        """symbol positions of the seek points of an n-symbol stream cut into `seek_points` pieces (the rule of
+        csrc/codec.hip): multiples of 64 near k n / S, ascending, inside (0, n); none for streams under 65536 symbols"""
+        if seek_points < 2 or n < 65536:
+            return []
+        out = []
+        for k in range(1, seek_points):
+            i = (n * k // seek_points) & ~63
+            if 0 < i < n and (not out or i > out[-1]):
+                out.append(i)
+        return out
+
+    def rans_encode_seek(self, sym, idx, which, seek_points):
+        """(stream, trailer): the stream of rans_encode and this build's "PCSK" trailer (b"" when the stream has no seek
+        points): "PCSK" | int32 count | count x (int32 index | uint64 state | int32 words consumed), big-endian"""
+        cdf, sizes, offs = self._tables(which)
+        sym = np.ascontiguousarray(sym, dtype=np.int32).reshape(-1)
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1)
+        si = np.asarray(self.seek_indexes(sym.shape[0], seek_points), dtype=np.int64)
+        st = np.zeros(max(len(si), 1), dtype=np.uint64)
+        wd = np.zeros(max(len(si), 1), dtype=np.int64)
+        cap = 8 * sym.shape[0] + 64
+        out = np.empty(cap, dtype=np.uint8)
+        self.lib.orc_rans_encode_seek.restype = C.c_int64
+        n = self.lib.orc_rans_encode_seek(_p(sym), _p(idx), C.c_int64(sym.shape[0]), _p(cdf), C.c_int(cdf.shape[1]),
+                                          _p(sizes), _p(offs), _p(out), C.c_int64(cap), _p(si) if len(si) else None,
+                                          C.c_int(len(si)), _p(st), _p(wd))
+        assert n >= 0
+        trailer = b""
+        if len(si):
+            trailer = b"PCSK" + struct.pack(">i", len(si)) + b"".join(
+                struct.pack(">iQi", int(si[k]), int(st[k]), int(wd[k])) for k in range(len(si)))
+        return out[:n].tobytes(), trailer
+
     def rans_decode(self, data, idx, which):
         cdf, sizes, offs = self._tables(which)
         idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1)
@@ -352,7 +387,7 @@ class Oracle:
         times[key] = times.get(key, 0.0) + (t1 - t0)
         return t1
 
-    def compress(self, frames, settings, version=0):
+    def compress(self, frames, settings, version=0, seek_points=0):
         """frames: list of {"points": int[N,3], "colors": float[N,3]} -> ({1..Q: bytes}, debug dict).
         version 0: the reference's container (single rANS streams); 1: this build's flagged extension — the same
         fields, top byte of the first word 1, y / z strings in the interleaved form of the GPU coder"""
@@ -398,16 +433,23 @@ class Oracle:
         prm = np.where(rows[:, None] >= 0, params[np.maximum(rows, 0)], np.float32(0)).astype(np.float32)
         scale = np.concatenate([self.scale_nn([q]) + self.eps for q in settings], 0).astype(np.float32)
         sym, idx = self.gaussian_quant(y_sorted, prm, scale)
-        out, y_strings = {}, []
+        out, y_strings, trailers = {}, [], []
         for qi, q in enumerate(settings):
             if version == 1:
                 y_strings.append(self.rans_interleaved_encode(sym[qi], idx[qi], "gaussian_conditional"))
+                trailers.append(b"")
+            elif seek_points:
+                ys, tr = self.rans_encode_seek(sym[qi], idx[qi], "gaussian_conditional", seek_points)
+                y_strings.append(ys)
+                trailers.append(tr)
             else:
                 y_strings.append(self.rans_encode(sym[qi], idx[qi], "gaussian_conditional"))
+                trailers.append(b"")
         t0 = self._tick(times, "gaussian_model", t0)
         for qi, q in enumerate(settings):
+            # the trailer stands behind the last frame record: the reference's reader (and read_bitstream below) stops there
             out[qi + 1] = self.make_bitstream(y_strings[qi], z_string, y_sorted.shape[0], zsym.shape[1], points_streams,
-                                              k, q, version)
+                                              k, q, version) + trailers[qi]
         self._tick(times, "bitstream_writing", t0)
         self.enc_times = times
         dbg = {"ykeys": ykeys, "y": y, "k": k, "zkeys": zkeys, "z": z, "params_keys": pkeys, "params": params,

@@ -334,13 +334,20 @@ static void enc_put_bits(uint64_t* r, uint32_t** pp, uint32_t val, uint32_t nbit
   *r = (x << nbits) | val;
 }
 
-/* returns the number of bytes, or -1 */
-ORC_API int64_t orc_rans_encode(const int32_t* sym, const int32_t* idx, int64_t n, const int32_t* cdfs, int pitch,
-                                const int32_t* sizes, const int32_t* offsets, uint8_t* out, int64_t cap) {
+/* returns the number of bytes, or -1.  Seek points (this build's "PCSK" container trailer, which the reference's reader
+ * never sees — codec_parallel.py:200-213 reads exactly num_frames frame records): for every seek_index[k] in (0, n),
+ * ascending, the coder's state and the number of 32-bit words a decoder has consumed when symbol seek_index[k] is the
+ * next one it decodes (0 / 0 for an index outside (0, n)). */
+ORC_API int64_t orc_rans_encode_seek(const int32_t* sym, const int32_t* idx, int64_t n, const int32_t* cdfs, int pitch,
+                                     const int32_t* sizes, const int32_t* offsets, uint8_t* out, int64_t cap,
+                                     const int64_t* seek_index, int n_seek, uint64_t* seek_state, int64_t* seek_word) {
   const int64_t max_syms = n * 12 + 8;
   rsym* s = (rsym*)malloc(sizeof(rsym) * (size_t)max_syms);
+  int64_t* first = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_seek + 1));   /* entry of s[] where symbol seek_index[k] starts */
+  for (int k = 0; k < n_seek; ++k) first[k] = -1;
   int64_t ns = 0;
   for (int64_t i = 0; i < n; ++i) {
+    for (int k = 0; k < n_seek; ++k) if (seek_index[k] == i && i > 0) first[k] = ns;
     const int32_t ci = idx[i];
     const int32_t* cdf = cdfs + (int64_t)ci * pitch;
     const int32_t max_value = sizes[ci] - 2;
@@ -365,20 +372,30 @@ ORC_API int64_t orc_rans_encode(const int32_t* sym, const int32_t* idx, int64_t 
   uint32_t* end = buf + ns + 4;
   uint32_t* ptr = end;
   uint64_t r = RANS_L;
+  for (int k = 0; k < n_seek; ++k) { seek_state[k] = 0; seek_word[k] = 0; }
   while (ns > 0) {
     const rsym q = s[--ns];
     if (!q.bypass) enc_put(&r, &ptr, q.start, q.range, 16);
     else enc_put_bits(&r, &ptr, q.start, 4);
+    for (int k = 0; k < n_seek; ++k)
+      if (first[k] == ns) { seek_state[k] = r; seek_word[k] = (int64_t)(end - ptr); }   /* words emitted so far */
   }
   ptr -= 2;
   ptr[0] = (uint32_t)(r >> 0);
   ptr[1] = (uint32_t)(r >> 32);
   const int64_t nbytes = (int64_t)(end - ptr) * 4;
+  /* the decoder reads forwards: with m of the M + 2 words emitted at the point, it has consumed M + 2 - m when it gets there */
+  for (int k = 0; k < n_seek; ++k) if (first[k] >= 0) seek_word[k] = nbytes / 4 - seek_word[k];
   int64_t ret = -1;
   if (nbytes <= cap) { memcpy(out, ptr, (size_t)nbytes); ret = nbytes; }
   free(buf);
+  free(first);
   free(s);
   return ret;
+}
+ORC_API int64_t orc_rans_encode(const int32_t* sym, const int32_t* idx, int64_t n, const int32_t* cdfs, int pitch,
+                                const int32_t* sizes, const int32_t* offsets, uint8_t* out, int64_t cap) {
+  return orc_rans_encode_seek(sym, idx, n, cdfs, pitch, sizes, offsets, out, cap, NULL, 0, NULL, NULL);
 }
 
 ORC_API int orc_rans_decode(const uint8_t* in, int64_t len, const int32_t* idx, int64_t n, const int32_t* cdfs,

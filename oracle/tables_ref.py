@@ -18,7 +18,9 @@ def pmf_to_quantized_cdf(pmf, precision=16):
     """ops.cpp pmf_to_quantized_cdf, statement by statement"""
     cdf = [0]
     for p in pmf:
-        cdf.append(int(math.floor(float(f32(f32(p) * f32(1 << precision)) + f32(0.5)))))   # std::round, p >= 0
+        # std::round(float) for p >= 0: half away from zero.  The product is a float32; the + 0.5 must NOT be (the float just
+        # below 0.5 plus 0.5 rounds to 1.0 in float32 where std::round gives 0): it is exact in double
+        cdf.append(int(math.floor(float(f32(f32(p) * f32(1 << precision))) + 0.5)))
     total = sum(cdf)
     cdf = [((1 << precision) * c) // total for c in cdf]
     for i in range(1, len(cdf)):               # std::partial_sum

@@ -481,6 +481,11 @@ def test_pmf_to_quantized_cdf_known_answers():
         assert mk.pmf_to_quantized_cdf([0.6, 0.0, 0.3, 0.0, 0.1], 4).tolist() == [0, 9, 10, 14, 15, 16]
         assert mk.pmf_to_quantized_cdf([0.2, 0.55, 0.0, 0.25], 4).tolist() == [0, 2, 11, 12, 16]
         assert mk.pmf_to_quantized_cdf([2.5 / 16, 13.5 / 16], 4).tolist() == [0, 2, 16]
+        # the float just below 0.5: std::round(0.49999997f) = 0 — a float32 "+ 0.5f" would round the sum up to 1.0.
+        # p * 16 = nextafter(0.5, 0) for the first bin: round -> [0, 8, 8], sum 16 -> [0, 0, 8, 16]; the empty bin steals
+        # from the first bin with the smallest frequency > 1 (symbol 1, > i): cdf[1] += 1 -> [0, 1, 8, 16]
+        below_half = float(np.nextafter(np.float32(0.5), np.float32(0))) / 16
+        assert mk.pmf_to_quantized_cdf([below_half, 0.5, 0.5], 4).tolist() == [0, 1, 8, 16]
 
 
 def test_update_rebuilds_the_checkpoint_tables_bit_for_bit():

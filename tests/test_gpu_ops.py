@@ -303,7 +303,7 @@ def test_other_widths_stay_on_the_matrix_cores(rt):
         assert name(0, 27, ci, co) == "k_gconv_gen" and name(0, 8, ci, co) == "k_gconv_gen" and name(1, 27, ci, co) == "k_gconv_gen"
         if co <= 128:
             assert name(2, 8, ci, co) == "k_convT_mfma"
-    assert name(0, 27, 32, 32) == "k_gconv16" and name(0, 8, 32, 64) == "k_gconv16" and name(1, 27, 32, 32) == "k_gconv_gen"
+    assert name(0, 27, 32, 32) == "k_gconv16" and name(0, 8, 32, 64) == "k_gconv16" and name(1, 27, 32, 32) == "k_gconv16"
     assert [name(0, 27, 4, co) for co in (16, 32, 64, 128)] == ["k_gconv_first"] * 4
     assert name(0, 27, 3, 5) == "k_gconv_scalar" and name(2, 8, 3, 5) == "k_convT_scalar"
     assert name(2, 8, 32, 32) == "k_convT16" and name(2, 8, 32, 64) == "k_convT_mfma"
@@ -487,6 +487,75 @@ def test_conv_head_up_forms_the_child_rule_book_in_kernel(rt, oracle, kind, n):
     remap = rt.inverse_rows(keep_d, len(ckeys))
     got = host(rt.subset_map_up(dev(rt, nbr_p), keep_d, remap))
     assert np.array_equal(got, oracle.map27(ckeys[keep], 1))
+
+
+@pytest.mark.parametrize("n_par", [1, 7, 16, 21, 35])
+@pytest.mark.parametrize("relu", [True, False])
+def test_up_stage_kernels_stay_inside_their_outputs(rt, oracle, n_par, relu):
+    """k_gconv_up, k_convT16 and k_convT16p drop the stores of rows past the end through the bounds of their raw buffer
+    descriptors (no branch behind them): outputs allocated with a canary tail, parent counts that are not multiples of
+    the 16-parent windows / tiles — the tail must be untouched and the rows must equal the oracle's, with and without
+    the ReLU (the code paths of the epilogues differ)"""
+    rtm = pkg("runtime")
+    rng = np.random.default_rng(900 + n_par)
+    pts = _structured_cloud("dense", n_par)
+    pts[:, 1:] *= 2
+    pkeys = sorted_keys(oracle, pts)
+    assert len(pkeys) == n_par
+    nbr_p = oracle.map27(pkeys, 2)
+    ckeys = oracle.up(pkeys, 2)
+    nbr_c = oracle.map27(ckeys, 1)
+    n = len(ckeys)
+    x = rng.normal(size=(n, 32)).astype(np.float32)
+    w, b = _weights(rng, 27, 32, 32)
+    hw = rng.normal(0, 0.3, (32, 1)).astype(np.float32)
+    hb = rng.normal(0, 0.1, 1).astype(np.float32)
+    ref = oracle.sparse_conv(x, nbr_c, w, b, relu, siblings_first=True)
+    tail = 4096
+    canary = 12345.5
+    feats = torch.full((n * 32 + tail,), canary, dtype=torch.float32, device="cuda")
+    logits = torch.full((n + tail,), canary, dtype=torch.float32, device="cuda")
+    xd, nd, wd, bd, hwd, hbd = dev(rt, x), dev(rt, nbr_p), dev(rt, w), dev(rt, b), dev(rt, hw), dev(rt, hb)
+    rtm.check(rt.lib.pcc_sparse_conv_head_up(rt.ctx, rtm._ptr(xd), n_par, rtm._ptr(nd), nbr_p.shape[1], rtm._ptr(wd), rtm._ptr(bd),
+                                             1 if relu else 0, rtm._ptr(feats), rtm._ptr(hwd), rtm._ptr(hbd), rtm._ptr(logits)),
+              "pcc_sparse_conv_head_up")
+    f, lg = feats.cpu().numpy(), logits.cpu().numpy()
+    assert np.array_equal(f[:n * 32].reshape(n, 32), ref) and np.all(f[n * 32:] == canary)
+    assert np.array_equal(lg[:n], oracle.linear(ref, hw, hb)[:, 0]) and np.all(lg[n:] == canary)
+    # the up stage (k_convT16 for these sizes; k_convT16p from 4 tiles per resident wave on: the full-size tests)
+    w8, b8 = _weights(rng, 8, 32, 32)
+    xp = rng.normal(size=(n_par, 32)).astype(np.float32)
+    up = torch.full((n * 32 + tail,), canary, dtype=torch.float32, device="cuda")
+    xpd, w8d, b8d = dev(rt, xp), dev(rt, w8), dev(rt, b8)
+    rtm.check(rt.lib.pcc_convT_gen(rt.ctx, rtm._ptr(xpd), n_par, rtm._ptr(w8d), rtm._ptr(b8d), 32, 32, 1 if relu else 0,
+                                   rtm._ptr(up)), "pcc_convT_gen")
+    u = up.cpu().numpy()
+    assert np.array_equal(u[:n * 32].reshape(n, 32), oracle.convT(xp, w8, b8, relu)) and np.all(u[n * 32:] == canary)
+
+
+def test_persistent_up_stage_stays_inside_its_output(rt, oracle):
+    """k_convT16p (persistent waves, from 4 tiles of 16 parents per resident wave on): a parent count that is not a
+    multiple of 16, output with a canary tail, plain and gathered input rows"""
+    rtm = pkg("runtime")
+    rng = np.random.default_rng(31)
+    waves = 2 * 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    n_par = 16 * 4 * waves + 16 * 37 + 5
+    x = rng.normal(size=(n_par, 32)).astype(np.float32)
+    w8, b8 = _weights(rng, 8, 32, 32)
+    canary, tail = -777.25, 8192
+    ref = oracle.convT(x, w8, b8, True)
+    xd, w8d, b8d = dev(rt, x), dev(rt, w8), dev(rt, b8)
+    up = torch.full((8 * n_par * 32 + tail,), canary, dtype=torch.float32, device="cuda")
+    rtm.check(rt.lib.pcc_convT_gen(rt.ctx, rtm._ptr(xd), n_par, rtm._ptr(w8d), rtm._ptr(b8d), 32, 32, 1, rtm._ptr(up)), "pcc_convT_gen")
+    u = up.cpu().numpy()
+    assert np.array_equal(u[:8 * n_par * 32].reshape(-1, 32), ref) and np.all(u[8 * n_par * 32:] == canary)
+    rows = rng.permutation(n_par).astype(np.uint32)
+    up.fill_(canary)
+    rd = dev(rt, rows.view(np.int32))
+    rtm.check(rt.lib.pcc_convT_gen_gather(rt.ctx, rtm._ptr(xd), rtm._ptr(rd), n_par, rtm._ptr(w8d), rtm._ptr(b8d), 1, rtm._ptr(up)),
+              "pcc_convT_gen_gather")
+    u = up.cpu().numpy()
+    assert np.array_equal(u[:8 * n_par * 32].reshape(-1, 32), oracle.convT(x[rows], w8, b8, True)) and np.all(u[8 * n_par * 32:] == canary)
 
 
 @pytest.mark.parametrize("kind", ["dense", "dust"])
