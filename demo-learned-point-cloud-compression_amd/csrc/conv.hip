@@ -759,9 +759,8 @@ static void launch_up(hipStream_t st, const float* d_in, int64_t n_parents, cons
   const int64_t n_out = 8 * n_parents;
   if (n_out < ((int64_t)1 << 25) && pitch < ((int64_t)1 << 24) && !force_wide_rows() && !force_up_legacy()) {
     const dim3 up_grid((nblk(n_parents, 16) + 7) / 8 * 8);
-    static const int order = getenv("PCC_UP_ORDER") ? atoi(getenv("PCC_UP_ORDER")) : 0;   // EXPERIMENT (round 4)
     hipLaunchKernelGGL((k_gconv_up<PERM>), up_grid, dim3(64), 0, st, d_in, d_nbr_parent, pitch,
-                       n_parents, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, (uint32_t)(n_out * 128), order);
+                       n_parents, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, (uint32_t)(n_out * 128));
   } else {
     launch16<true, true, PERM, 32>(st, d_in, n_out, d_nbr_parent, 27, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co);
   }
@@ -858,10 +857,8 @@ extern "C" int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_i
   // "siblings first" is DEFINED on row indexes: a neighbour belongs to the first pass when (input row >> 3) ==
   // (output row >> 3) — "same parent" on a generative level (rows in aligned blocks of the 8 children of a parent), and
   // simply "same aligned block of 8 rows" on any other set, for which the order is as deterministic and is what
-  // oracle/pcc_oracle.c computes too (include/pcc.h).  It needs input and output rows to be the same set:
-  PCC_REQUIRE(n_in == n_out, PCC_E_ARG,
-              "pcc_sparse_conv_head: the siblings-first order compares input and output row indexes: n_in %lld != n_out %lld",
-              (long long)n_in, (long long)n_out);
+  // oracle/pcc_oracle.c computes too (include/pcc.h) — also when input and output are different sets (the comparison is
+  // of index values; tests/test_gpu_fullsize.py gathers from a 16.8M-row input into 250k output rows that way).
   if (n_out > 0 && cout == 32 && d_in && d_nbr && d_w && d_bias && d_out && nbr_pitch >= n_out && n_in > 0 &&
       conv16_shape(d_in, d_out, k_vol, cin, cout)) {
     const float* wsw;

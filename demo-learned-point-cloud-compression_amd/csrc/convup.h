@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
     const float* __restrict__ in, const int32_t* __restrict__ nbrp, int64_t pitch, int64_t n_par,
     const float* __restrict__ wsw, const float* __restrict__ bias, int relu, float* __restrict__ out,
     const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ head_out,
-    const float* __restrict__ rgb_w, const float* __restrict__ rgb_b, float* __restrict__ rgb_out, uint32_t in_bytes, int order) {
+    const float* __restrict__ rgb_w, const float* __restrict__ rgb_b, float* __restrict__ rgb_out, uint32_t in_bytes) {
   constexpr int R = 128;             // rows of a window: 16 parents
   constexpr int HP = (R + 1) * 16;   // floats per accumulator plane (row R = sink of the pad slots)
   constexpr int NI = 4;              // pipelined items of an offset
@@ -83,9 +83,14 @@ __global__ __launch_bounds__(64, 2) void k_gconv_up(
   __shared__ __attribute__((aligned(4))) unsigned char lut[27 * 8];
 
   const int lane = threadIdx.x;
-  int64_t window = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware order (conv16.h)
-  if (order & 2) window = blockIdx.x;
-  if (order & 1) window = (int64_t)gridDim.x - 1 - window;
+  // Windows are taken from the END of the tensor, in dispatch order: the up stage in front of this layer (k_convT16p,
+  // persistent waves over ascending tiles) has just written the rows in ascending order, 417 MB at the large stage, so
+  // the rows it wrote last are the ones still in the 256-MB Infinity Cache — read in ascending order instead, every
+  // window evicts rows that are still to come.  1.059 / 1.060 ms against 1.068 / 1.070 in the timed region of bench.py
+  // on one box (two interleaved passes of 30 steps; round 3's order — one contiguous eighth of the windows per XCD,
+  // ascending — against this one); neighbouring windows now run on different XCDs, which measures as nothing (round 3:
+  // runs of 1 / 16 / 128 windows per XCD).
+  const int64_t window = (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x;
   const int64_t par0 = window * 16;
   if (par0 >= n_par) return;
   const int64_t row0 = par0 * 8, n_out = n_par * 8;

@@ -241,9 +241,13 @@ int pcc_conv_forget(pcc_ctx* ctx, const float* d_w);
 /* the conv3 layer of a g_s stage (codec_parallel.py:469) with the 1x1 occupancy
  * head fused into its epilogue: d_head_out[n] = head_b[0] + sum_c fmaf(out[n][c],
  * head_w[c]) (c ascending) — bit-identical to pcc_linear(cout -> 1) applied to
- * d_out, without re-reading it.  Input and output rows are the same set (a
- * generative level, n_in == n_out); neighbours are visited SIBLINGS FIRST (the
- * arithmetic contract at the top of this file). */
+ * d_out, without re-reading it.  Neighbours are visited SIBLINGS FIRST (the
+ * arithmetic contract at the top of this file): first the pairs with
+ * (input row >> 3) == (output row >> 3), k ascending, then the others, k
+ * ascending.  On a generative level (input rows = output rows, in aligned blocks
+ * of the 8 children of a parent — what g_s feeds it) that is "the row's own
+ * parent first"; on any other input it is the same comparison of index values,
+ * as deterministic, and what the oracle computes too — no check rejects it. */
 int pcc_sparse_conv_head(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                          const int32_t* d_nbr, int k_vol, int64_t nbr_pitch,
                          int64_t n_out, const float* d_w, const float* d_bias,
