@@ -14,8 +14,15 @@
 //   chunk c, lane l : nodes [(64 c + l) S, (64 c + l + 1) S) below n_nodes = sum(level_n)
 //   step t = 8 s + j: every lane codes bit j of its node s (nothing when the node does not exist or the bit is
 //                     implied: j == 7 behind seven zeros)
-//   payload         = 64 x (state lo, state hi) | block(step 0) | block(step 1) ..; a block holds the 16-bit words the
-//                     decoder's lanes need after that step, in ascending lane order
+//   payload         = 64 x (state lo, state hi) | u16 len[64] | words of lane 0 | words of lane 1 | ..: every lane has
+//                     its own run of 16-bit renormalisation words, in the order its decoder consumes them
+//
+// (The first form of this round shared one word sequence per chunk — blocks per step, a lane's place by ballot + mbcnt,
+// as the y / z coder of container version 1 does: 0.92 / 1.04 ms per coder launch for the sweep, i.e. ~0.25 us per
+// step: a lone wave issues one instruction every ~5 cycles whether or not it depends on the one before, and a step was
+// ~100 instructions — the refill's ballot, two ds_bpermute and window bookkeeping, a 64-bit-float division per
+// decision in the encoder.  Per-lane runs need none of that: a refill is a shift and an LDS read of the lane's own next
+// word, the division a lookup of 2^32 / freq in a 16-KB LDS table; 128 B of length table per chunk: +0.9 % bytes.)
 //
 // A lane's model starts from the frame's average probability per context (p0: a counting pass, 216 B of header)
 // instead of 1/2, so that a run of 512 nodes does not pay for learning it again: +2.7 % bytes against version 1 on
@@ -95,22 +102,46 @@ __global__ __launch_bounds__(256) void k_o2_stats(const uint8_t* __restrict__ oc
     if (s_cnt[i]) atomicAdd(&cnt[i], s_cnt[i]);
 }
 
+// floor(2^32 / f) for f = 1 .. 4095 (entry 0 and 1 unused: a frequency is 15 .. 4081): x / f for x < 2^32 is
+// mulhi(x, rcp[f]) or one more (checked by the remainder)
+struct O2Rcp {
+  uint32_t v[4096];
+};
+__host__ __device__ constexpr O2Rcp o2_rcp_table() {
+  O2Rcp t{};
+  for (int f = 2; f < 4096; ++f) t.v[f] = (uint32_t)(0x100000000ull / (uint64_t)f);
+  t.v[0] = 0;
+  t.v[1] = 0xFFFFFFFFu;
+  return t;
+}
+__device__ const O2Rcp kO2Rcp = o2_rcp_table();
+
 // One wave per chunk.  Forward pass: every lane walks its S nodes with its own model and leaves one record per step
-// (probability of a one | bit << 15, 0 = nothing coded) in rec[chunk][step][lane]; backward pass: the rANS steps in
-// reverse, renormalisation words packed downwards from the end of the chunk's private buffer (ballot + mbcnt give a
-// lane its place in a block).  As in rans_gpu.hip every global access of the coding loop is unconditional.
+// (probability of a one | bit << 15, 0 = nothing coded) in rec[chunk][step][lane]; backward pass: the lane's rANS steps
+// in reverse, every renormalisation word stored downwards from the end of the lane's own T-word region of `work`
+// ([chunk][lane][T]: a step emits at most one word).  states[chunk][128] and lens[chunk][64] receive the final states
+// and the word counts; words_out[chunk] = 192 + sum of the counts.  Every global access of the coding loop is
+// unconditional (rans_gpu.hip's rule).
 __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ32, int64_t n_nodes, int64_t start_last,
                                                int64_t start_prev, int S, const uint32_t* __restrict__ cnt,
-                                               uint16_t* __restrict__ rec, uint16_t* __restrict__ work, int64_t cap_words,
+                                               uint16_t* __restrict__ rec, uint16_t* __restrict__ work,
+                                               uint16_t* __restrict__ states, uint16_t* __restrict__ lens,
                                                uint32_t* __restrict__ words_out, uint16_t* __restrict__ p0_out) {
   __shared__ uint16_t s_model[kCtx * kLanes];   // [ctx][lane]
   __shared__ uint16_t s_p0[kCtx];
+  __shared__ __attribute__((aligned(16))) uint32_t s_rcp[4096];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
   for (int ctx = lane; ctx < kCtx; ctx += kLanes) {
     const uint32_t p = o2_p0(cnt[2 * ctx], cnt[2 * ctx + 1]);
     s_p0[ctx] = (uint16_t)p;
     if (c == 0) p0_out[ctx] = (uint16_t)p;
+  }
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(kO2Rcp.v);
+    uint4* dst = reinterpret_cast<uint4*>(s_rcp);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[lane + 64 * i] = src[lane + 64 * i];
   }
   __syncthreads();
   for (int ctx = 0; ctx < kCtx; ++ctx) s_model[ctx * kLanes + lane] = s_p0[ctx];
@@ -144,41 +175,29 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
       }
     }
   }
-  __threadfence_block();
 
   // backward pass
-  uint16_t* buf = work + c * cap_words;
-  int64_t ptr = cap_words;   // 16-bit words [ptr, cap_words) are written
-  bool overflow = false;
+  uint16_t* reg_w = reinterpret_cast<uint16_t*>(uniform_u64((uint64_t)(work + c * kLanes * T)));
+  const __amdgpu_buffer_rsrc_t reg_rs = __builtin_amdgcn_make_buffer_rsrc(reg_w, 0, (int)(uint32_t)(kLanes * T * 2), 0x00027000);
+  int wp = (int)T;            // words [wp, T) of the lane's region are written
+  const uint32_t lane_off = (uint32_t)lane * (uint32_t)T * 2u;
   uint32_t x = kL;
-  uint16_t* buf_w = reinterpret_cast<uint16_t*>(uniform_u64((uint64_t)buf));
-  const __amdgpu_buffer_rsrc_t buf_rs = __builtin_amdgcn_make_buffer_rsrc(buf_w, 0, (int)(uint32_t)(cap_words * 2), 0x00027000);
-  auto emit = [&](bool need) {
-    const unsigned long long bal = __ballot(need);
-    const int n_w = __popcll(bal);
-    const bool room = ptr - n_w >= 2 * kLanes;
-    overflow |= !room;
-    ptr -= room ? n_w : 0;
-    const uint32_t off = (need && room) ? (uint32_t)(ptr + lane_rank(bal)) * 2u : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x, buf_rs, off, 0, 0);
-  };
   constexpr int kAhead = 8;   // T is a multiple of 8
   uint32_t r_q[kAhead];
   auto fetch = [&](int64_t t) -> uint32_t { return recw[(t >= 0 ? t : 0) * kLanes + lane]; };
 #pragma unroll
   for (int d = 0; d < kAhead; ++d) r_q[d] = fetch(T - 1 - d);
   struct Prep {
-    uint32_t freq, start;
+    uint32_t freq, start, rcp;
     bool act;
-    double rinv;
   };
-  auto prep = [&](uint32_t r) -> Prep {
+  auto prep = [&](uint32_t r) -> Prep {   // one step ahead: the LDS lookup has a whole step to arrive in
     const uint32_t p1 = r & 0xFFFu, bit = r >> 15;
     Prep q;
     q.act = r != 0u;
     q.freq = bit ? p1 : 4096u - p1;
     q.start = bit ? 4096u - p1 : 0u;
-    q.rinv = 1.0 / (double)q.freq;
+    q.rcp = s_rcp[q.freq & 4095u];
     return q;
   };
   Prep cur = prep(r_q[0]);
@@ -189,25 +208,27 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
       r_q[d] = fetch(t - kAhead);
       const Prep nxt = prep(t > 0 ? r_q[(d + 1) % kAhead] : 0u);
       const bool need = cur.act && x >= (cur.freq << 20);   // ((L >> 12) << 16) * freq; freq <= 4081
-      emit(need);
+      wp -= need ? 1 : 0;
+      __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x, reg_rs, need ? lane_off + (uint32_t)wp * 2u : 0xFFFFFFF0u, 0, 0);
       if (need) x >>= 16;
       if (cur.act) {
-        // x / freq with x < 2^20 freq: quotient from one multiplication by 1 / freq in double, corrected by the remainder
-        uint32_t qd = (uint32_t)((double)x * cur.rinv);
-        int64_t rem = (int64_t)x - (int64_t)qd * cur.freq;
-        if (rem < 0) { --qd; rem += (int64_t)cur.freq; }
-        else if (rem >= (int64_t)cur.freq) { ++qd; rem -= (int64_t)cur.freq; }
-        x = (qd << 12) + (uint32_t)rem + cur.start;
+        // x / freq with x < 2^20 freq: mulhi by floor(2^32 / freq) is the quotient or one less
+        uint32_t qd = __umulhi(x, cur.rcp);
+        uint32_t rem = x - qd * cur.freq;
+        if (rem >= cur.freq) { ++qd; rem -= cur.freq; }
+        x = (qd << 12) + rem + cur.start;
       }
       cur = nxt;
     }
   }
-  if (!overflow) {
-    ptr -= 2 * kLanes;
-    buf[ptr + 2 * lane] = (uint16_t)x;
-    buf[ptr + 2 * lane + 1] = (uint16_t)(x >> 16);
-  }
-  if (lane == 0) words_out[c] = overflow ? 0xFFFFFFFFu : (uint32_t)(cap_words - ptr);
+  states[c * 2 * kLanes + 2 * lane] = (uint16_t)x;
+  states[c * 2 * kLanes + 2 * lane + 1] = (uint16_t)(x >> 16);
+  const uint32_t len = (uint32_t)((int)T - wp);
+  lens[c * kLanes + lane] = (uint16_t)len;
+  uint32_t tot = len;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += (uint32_t)__shfl_xor((int)tot, d, 64);
+  if (lane == 0) words_out[c] = 3u * kLanes + tot;
 }
 
 struct O2Head {
@@ -218,23 +239,19 @@ struct O2Head {
 };
 
 // the blob, assembled where `out` points (pinned host memory: the bytes cross PCIe as the kernel writes them):
-// workgroup c < nc moves chunk c, workgroup nc writes the header; *len_out = bytes, or -1 (a chunk overflowed / cap)
-__global__ __launch_bounds__(256) void k_o2_pack(const uint16_t* __restrict__ work, int64_t cap_words,
+// workgroup c < nc moves chunk c (states, length table, the 64 runs), workgroup nc writes the header; *len_out = bytes,
+// or -1 (cap)
+__global__ __launch_bounds__(256) void k_o2_pack(const uint16_t* __restrict__ work, int64_t T,
+                                                 const uint16_t* __restrict__ states, const uint16_t* __restrict__ lens,
                                                  const uint32_t* __restrict__ words, const uint32_t* __restrict__ counts,
                                                  const uint16_t* __restrict__ p0, O2Head h, uint8_t* __restrict__ out,
                                                  int64_t cap, long long* __restrict__ len_out) {
   __shared__ unsigned long long s_sum[256];
-  __shared__ int s_bad;
+  __shared__ uint32_t s_off[kLanes + 1];
   const int64_t c = blockIdx.x, nc = h.nc;
-  if (threadIdx.x == 0) s_bad = 0;
-  __syncthreads();
   unsigned long long part = 0;
   const int64_t upto = c < nc ? c : nc;
-  for (int64_t j = threadIdx.x; j < nc; j += blockDim.x) {
-    const uint32_t v = words[j];
-    if (v == 0xFFFFFFFFu) s_bad = 1;
-    if (j < upto) part += v;
-  }
+  for (int64_t j = threadIdx.x; j < upto; j += blockDim.x) part += words[j];
   s_sum[threadIdx.x] = part;
   __syncthreads();
   for (int d = 128; d >= 1; d >>= 1) {
@@ -242,11 +259,10 @@ __global__ __launch_bounds__(256) void k_o2_pack(const uint16_t* __restrict__ wo
     __syncthreads();
   }
   const unsigned long long before = s_sum[0];
-  const bool bad = s_bad != 0;
   const unsigned long long head = (unsigned long long)kHeader + 4ull * h.depth + 8ull + 2ull * kCtx + 4ull * nc;
   if (c == nc) {
     const unsigned long long total = head + before * 2;
-    const bool fits = !bad && (long long)total <= cap;
+    const bool fits = (long long)total <= cap;
     if (threadIdx.x == 0) {
       *len_out = fits ? (long long)total : -1;
       __threadfence_system();
@@ -270,25 +286,26 @@ __global__ __launch_bounds__(256) void k_o2_pack(const uint16_t* __restrict__ wo
     for (int64_t j = threadIdx.x; j < nc; j += blockDim.x) tab[j] = words[j];
     return;
   }
-  if (bad) return;
   const uint32_t cw = words[c];
   if ((long long)(head + (before + cw) * 2) > cap) return;   // the header block reports it
-  const uint16_t* src = work + c * cap_words + (cap_words - cw);
   uint16_t* dst = reinterpret_cast<uint16_t*>(out + head) + before;
-  // 16-bit words in pairs where source and destination allow it (both sides 4-byte aligned after at most one word)
-  uint32_t j0 = 0;
-  if ((((uintptr_t)dst) & 2) && cw) {
-    if (threadIdx.x == 0) dst[0] = src[0];
-    j0 = 1;
+  if (threadIdx.x == 0) {   // where every lane's run starts (words behind the states and the length table)
+    uint32_t off = 3u * kLanes;
+    for (int l = 0; l < kLanes; ++l) {
+      s_off[l] = off;
+      off += lens[c * kLanes + l];
+    }
+    s_off[kLanes] = off;
   }
-  if ((((uintptr_t)(src + j0)) & 2) == 0) {
-    const uint32_t pairs = (cw - j0) / 2;
-    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src + j0);
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + j0);
-    for (uint32_t j = threadIdx.x; j < pairs; j += blockDim.x) d32[j] = s32[j];
-    if (((cw - j0) & 1) && threadIdx.x == 0) dst[cw - 1] = src[cw - 1];
-  } else {
-    for (uint32_t j = j0 + threadIdx.x; j < cw; j += blockDim.x) dst[j] = src[j];
+  if (threadIdx.x < 2 * kLanes) dst[threadIdx.x] = states[c * 2 * kLanes + threadIdx.x];
+  if (threadIdx.x < kLanes) dst[2 * kLanes + threadIdx.x] = lens[c * kLanes + threadIdx.x];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  for (int l = wave; l < kLanes; l += 4) {
+    const uint32_t n_w = s_off[l + 1] - s_off[l];
+    const uint16_t* src = work + (c * kLanes + l) * T + (T - n_w);
+    uint16_t* d = dst + s_off[l];
+    for (uint32_t j = ln; j < n_w; j += 64) d[j] = src[j];
   }
 }
 
@@ -299,76 +316,69 @@ struct O2Offs {
   int64_t off[18];   // off[L] = nodes in front of level L; off[depth] = n_nodes; off[depth + 1] = n_nodes + n_points
 };
 
-__global__ __launch_bounds__(64) void k_o2_dec(const uint16_t* __restrict__ p0, const uint32_t* __restrict__ table,
-                                               const uint16_t* __restrict__ payload, int64_t n_nodes, int64_t start_last,
-                                               int64_t start_prev, int S, uint32_t* __restrict__ occ32,
-                                               int32_t* __restrict__ status) {
-  __shared__ uint16_t s_model[kCtx * kLanes];
-  const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
-  for (int ctx = 0; ctx < kCtx; ++ctx) s_model[ctx * kLanes + lane] = p0[ctx];
-  unsigned long long before = 0;
-  for (int64_t j = lane; j < c; j += kLanes) before += table[j];
-  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
-  const uint32_t cw = table[c];
-  const uint16_t* p = payload + before;
-  int bad = 0;
-  if (cw < 2 * kLanes) {
-    if (lane == 0) atomicOr(status, 1);
+// the chunk's words in LDS when they fit (a chunk is 64 S nodes: <= 32 KB of payload for S = 512 unless the stream was
+// made to cost more than 8 bits per node), else read from the stream where they lie (slow, correct)
+constexpr int kDecLdsWords = 24576;   // 48 KB beside the 13.8 KB of models
+
+template <bool IN_LDS>
+__device__ __forceinline__ void o2_decode_chunk(uint16_t* s_model, const uint16_t* __restrict__ s_words,
+                                                const uint16_t* __restrict__ p /* the chunk in the stream */, uint32_t cw,
+                                                int64_t c, int lane, int64_t n_nodes, int64_t start_last, int64_t start_prev,
+                                                int S, uint32_t* __restrict__ occ32, int& bad) {
+  uint32_t x = (uint32_t)p[2 * lane] | ((uint32_t)p[2 * lane + 1] << 16);
+  // the lane's run: [rbase, rend) in 16-bit words from the chunk's start
+  const uint32_t my_len = p[2 * kLanes + lane];
+  uint32_t incl = my_len;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    incl += lane >= d ? o : 0u;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+  if (3u * kLanes + total != cw) {   // wave-uniform
+    bad |= 1;
     return;
   }
-  uint32_t x = (uint32_t)p[2 * lane] | ((uint32_t)p[2 * lane + 1] << 16);
-  int64_t ptr = 2 * kLanes;
-  // the chunk's words behind a buffer descriptor over its aligned dwords, 128 at a time in two registers per lane
-  // (rans_gpu.hip: k_rans_dec)
-  const uint64_t p_u = uniform_u64((uint64_t)p);
-  const int mis = (int)((p_u >> 1) & 1);
-  const uint32_t cw_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw);
-  const uint32_t cw_u = cw_r < 0x3FFFFFF0u ? cw_r : 0x3FFFFFF0u;
-  const __amdgpu_buffer_rsrc_t win_rs = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(p_u & ~(uint64_t)3), 0, (int)((((cw_u + (uint32_t)mis) * 2u) + 3u) & ~3u), 0x00027000);
-  auto window = [&](int64_t at) -> uint32_t {
-    return __builtin_amdgcn_raw_buffer_load_b32(win_rs, (uint32_t)(((at + lane + mis) >> 1) << 2), 0, 0);
+  const uint32_t rbase = 3u * kLanes + incl - my_len, rend = rbase + my_len;
+  uint32_t pos = rbase;   // next word of the run
+  auto word_at = [&](uint32_t i) -> uint32_t {
+    const uint32_t ic = i < cw ? i : cw - 1;   // a lane at the end of the chunk's last run looks one word too far: never used
+    if constexpr (IN_LDS) return s_words[ic];
+    return p[ic];
   };
-  int64_t wb = ptr & ~(int64_t)63;
-  uint32_t win_a = window(wb), win_b = window(wb + 64);
-  auto refill = [&](bool need) {
-    const unsigned long long bal = __ballot(need);
-    const int n_w = __popcll(bal);
-    const int at = (int)(ptr - wb) + lane_rank(bal);   // 0 .. 126
-    const uint32_t wa = (uint32_t)__shfl((int)win_a, at & 63, 64), wbv = (uint32_t)__shfl((int)win_b, at & 63, 64);
-    const uint32_t dw = at < 64 ? wa : wbv;
-    const uint32_t w = (dw >> (16 * ((at + mis) & 1))) & 0xFFFFu;
-    const bool fits = ptr + n_w <= (int64_t)cw;
-    if (!fits && n_w) bad |= 1;
-    if (need) x = fits ? (x << 16) | w : kL;
-    ptr += fits ? n_w : 0;
-    const bool cross = ptr - wb >= 64;   // wave-uniform
-    wb += cross ? 64 : 0;
-    win_a = cross ? win_b : win_a;
-  };
-  auto request_b = [&]() { win_b = window(wb + 64); };
-
+  uint32_t nextw = word_at(pos);
   const int64_t node0 = (c * kLanes + lane) * S;
   // the lane's bytes leave as dwords (node0 and S are multiples of 4) through a descriptor over the node array padded
   // to a whole dword: a lane past the end stores beyond it (dropped)
   const __amdgpu_buffer_rsrc_t occ_rs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(uniform_u64((uint64_t)occ32)), 0,
       __builtin_amdgcn_readfirstlane((int)(uint32_t)(((n_nodes + 3) >> 2) << 2)), 0x00027000);
+  auto cls_of = [&](int64_t node) -> int { return node >= start_last ? 0 : (node >= start_prev ? 1 : 2); };
+  // the model entry of the NEXT decision is requested before the current one is decoded — both candidates (the ones
+  // so far, and one more) — so that the LDS round trip is not on the chain from state to state
+  uint32_t p_cur = s_model[(cls_of(node0) * 36) * kLanes + lane];
   for (int s = 0; s < S; s += 4) {
     uint32_t dw = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t node = node0 + s + q;
       const bool valid = node < n_nodes;
-      const int cls = node >= start_last ? 0 : (node >= start_prev ? 1 : 2);
+      const int cbase = cls_of(node) * 36;
       int ones = 0;
       uint32_t byte = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        const int at = (cbase + j * (j + 1) / 2 + ones) * kLanes + lane;
+        uint32_t c0, c1 = 0;
+        if (j < 7) {
+          const int an = (cbase + (j + 1) * (j + 2) / 2 + ones) * kLanes + lane;
+          c0 = s_model[an];
+          c1 = s_model[an + kLanes];
+        } else {
+          c0 = s_model[(cls_of(node + 1) * 36) * kLanes + lane];   // decision 0 of the next node
+        }
         const bool act = valid && !(j == 7 && ones == 0);
-        const int at = (cls * 36 + j * (j + 1) / 2 + ones) * kLanes + lane;
-        const uint32_t p1 = s_model[at];
+        const uint32_t p1 = p_cur;
         const uint32_t cum = x & 4095u;
         uint32_t bit = cum >= 4096u - p1 ? 1u : 0u;
         const uint32_t start = bit ? 4096u - p1 : 0u, freq = bit ? p1 : 4096u - p1;
@@ -378,17 +388,60 @@ __global__ __launch_bounds__(64) void k_o2_dec(const uint16_t* __restrict__ p0, 
         } else {
           bit = valid ? 1u : 0u;   // the implied bit
         }
-        refill(act && x < kL);
-        request_b();
+        const bool need = act && x < kL;
+        if (need) {
+          if (pos >= rend) bad |= 1;
+          x = (x << 16) | nextw;
+          ++pos;
+          nextw = word_at(pos);
+        }
         ones += (int)bit;
         byte |= bit << j;
+        p_cur = (j < 7 && bit) ? c1 : c0;
       }
       if (valid && byte == 0u) bad |= 2;
       dw |= byte << (8 * q);
     }
     __builtin_amdgcn_raw_buffer_store_b32(dw, occ_rs, (uint32_t)(node0 + s), 0, 0);
   }
-  if (ptr != (int64_t)cw) bad |= 1;
+  if (pos != rend) bad |= 1;   // every word of the run consumed
+}
+
+__global__ __launch_bounds__(64) void k_o2_dec(const uint16_t* __restrict__ p0, const uint32_t* __restrict__ table,
+                                               const uint16_t* __restrict__ payload, int64_t n_nodes, int64_t start_last,
+                                               int64_t start_prev, int S, uint32_t* __restrict__ occ32,
+                                               int32_t* __restrict__ status) {
+  __shared__ uint16_t s_model[kCtx * kLanes];
+  __shared__ __attribute__((aligned(16))) uint16_t s_words[kDecLdsWords];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  for (int ctx = 0; ctx < kCtx; ++ctx) s_model[ctx * kLanes + lane] = p0[ctx];
+  unsigned long long before = 0;
+  for (int64_t j = lane; j < c; j += kLanes) before += table[j];
+  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+  const uint32_t cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)table[c]);
+  const uint16_t* p = payload + before;
+  int bad = 0;
+  if (cw < 3 * kLanes) {
+    if (lane == 0) atomicOr(status, 1);
+    return;
+  }
+  if (cw <= (uint32_t)kDecLdsWords) {
+    // the chunk into LDS: dwords from the aligned address at or below its first word
+    const int mis = (int)(((uintptr_t)p >> 1) & 1);
+    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(p - mis);
+    const uint32_t n_dw = (cw + (uint32_t)mis + 1u) >> 1;
+    for (uint32_t i = lane; i < n_dw; i += kLanes) {
+      const uint32_t v = p32[i];
+      const int w0 = 2 * (int)i - mis;
+      if (w0 >= 0 && w0 < (int)cw) s_words[w0] = (uint16_t)v;
+      if (w0 + 1 >= 0 && w0 + 1 < (int)cw) s_words[w0 + 1] = (uint16_t)(v >> 16);
+    }
+    __syncthreads();
+    o2_decode_chunk<true>(s_model, s_words, p, cw, c, lane, n_nodes, start_last, start_prev, S, occ32, bad);
+  } else {
+    o2_decode_chunk<false>(s_model, s_words, p, cw, c, lane, n_nodes, start_last, start_prev, S, occ32, bad);
+  }
   const unsigned long long b1 = __ballot((bad & 1) != 0), b2 = __ballot((bad & 2) != 0);
   if (lane == 0 && (b1 | b2) != 0ull) atomicOr(status, (b1 ? 1 : 0) | (b2 ? 2 : 0));
 }
@@ -480,7 +533,7 @@ int pcc_octree2_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_
   auto coder_bytes = [](int64_t nodes) -> size_t {
     const O2Layout l = o2_layout(nodes);
     const int64_t T = 8 * l.S;
-    return (size_t)l.nc * ((size_t)T * kLanes * 2 + (size_t)(2 * kLanes + kLanes * T) * 2 + 4) + 3 * 256 + 4096;
+    return (size_t)l.nc * ((size_t)T * kLanes * 2 * 2 + 4 + 3 * kLanes * 2) + 3 * 256 + 4096;   // records, word regions, tables
   };
   PCC_TRY(pcc_arena_reserve(ctx, cap_occ + pcc_octree_wave_scratch(n) + coder_bytes(nodes_guess) + 16384));
   uint8_t* occ = (uint8_t*)pcc_arena_alloc(ctx, cap_occ + 16);
@@ -504,25 +557,29 @@ int pcc_octree2_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_
   const int64_t start_last = n_nodes - (int64_t)hc[depth - 1];
   const int64_t start_prev = depth >= 2 ? start_last - (int64_t)hc[depth - 2] : 0;
   const O2Layout lay = o2_layout(n_nodes);
-  const int64_t T = 8 * lay.S, cap_words = 2 * kLanes + kLanes * T;
+  const int64_t T = 8 * lay.S, cap_words = 3 * kLanes + kLanes * T;   // bound of a chunk in the blob
   struct Own {   // the rare block of its own, freed on every way out
     void* p = nullptr;
     ~Own() { if (p) (void)hipFree(p); }
   } own;
-  const size_t rec_b = pcc_align((size_t)lay.nc * T * kLanes * 2), work_b = pcc_align((size_t)lay.nc * cap_words * 2);
+  const size_t rec_b = pcc_align((size_t)lay.nc * T * kLanes * 2), work_b = rec_b;   // [chunk][step][lane] / [chunk][lane][T]
+  const size_t small_b = pcc_align((size_t)lay.nc * (4 + 2 * kLanes * 2 + kLanes * 2));   // words | states | lens
   uint16_t *rec, *work;
-  uint32_t* words;
-  if (pcc_align(ctx->arena_off) + rec_b + work_b + pcc_align((size_t)lay.nc * 4) + 1024 <= ctx->arena_cap) {
+  char* small;
+  if (pcc_align(ctx->arena_off) + rec_b + work_b + small_b + 1024 <= ctx->arena_cap) {
     rec = (uint16_t*)pcc_arena_alloc(ctx, rec_b);
     work = (uint16_t*)pcc_arena_alloc(ctx, work_b);
-    words = (uint32_t*)pcc_arena_alloc(ctx, (size_t)lay.nc * 4);
+    small = (char*)pcc_arena_alloc(ctx, small_b);
   } else {
-    PCC_HIP(hipMalloc(&own.p, rec_b + work_b + pcc_align((size_t)lay.nc * 4)));
+    PCC_HIP(hipMalloc(&own.p, rec_b + work_b + small_b));
     rec = (uint16_t*)own.p;
     work = (uint16_t*)((char*)own.p + rec_b);
-    words = (uint32_t*)((char*)own.p + rec_b + work_b);
+    small = (char*)own.p + rec_b + work_b;
   }
-  if (!rec || !work || !words) return PCC_E_NOMEM;
+  if (!rec || !work || !small) return PCC_E_NOMEM;
+  uint32_t* words = (uint32_t*)small;
+  uint16_t* states = (uint16_t*)(small + (size_t)lay.nc * 4);
+  uint16_t* lens = states + (size_t)lay.nc * 2 * kLanes;
   const int64_t head = kHeader + 4 * depth + 8 + 2 * kCtx + 4 * lay.nc;
   const int64_t bound = head + 2 * lay.nc * cap_words;
   const int64_t cap_blob = std::min<int64_t>(bound, std::max<int64_t>(cap, head));
@@ -533,7 +590,7 @@ int pcc_octree2_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_
                      start_last, start_prev, cnt);
   PCC_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_o2_enc, dim3((unsigned)lay.nc), dim3(64), 0, st, (const uint32_t*)occ, n_nodes, start_last, start_prev,
-                     (int)lay.S, (const uint32_t*)cnt, rec, work, cap_words, words, p0);
+                     (int)lay.S, (const uint32_t*)cnt, rec, work, states, lens, words, p0);
   PCC_CHECK_LAUNCH();
   O2Head h;
   h.depth = depth;
@@ -541,8 +598,9 @@ int pcc_octree2_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_
   for (int a = 0; a < 3; ++a) h.origin[a] = origin[a];
   h.S = (uint32_t)lay.S;
   h.nc = (uint32_t)lay.nc;
-  hipLaunchKernelGGL(k_o2_pack, dim3((unsigned)lay.nc + 1), dim3(256), 0, st, (const uint16_t*)work, cap_words,
-                     (const uint32_t*)words, (const uint32_t*)counts, (const uint16_t*)p0, h, stage, cap_blob, len_dev);
+  hipLaunchKernelGGL(k_o2_pack, dim3((unsigned)lay.nc + 1), dim3(256), 0, st, (const uint16_t*)work, T, (const uint16_t*)states,
+                     (const uint16_t*)lens, (const uint32_t*)words, (const uint32_t*)counts, (const uint16_t*)p0, h, stage,
+                     cap_blob, len_dev);
   PCC_CHECK_LAUNCH();
   PCC_HIP(hipStreamSynchronize(st));
   const long long total = *(volatile long long*)len_dev;
@@ -600,7 +658,7 @@ static int o2_parse(const uint8_t* h_in, int64_t len, O2Info* o) {
   int64_t words = 0;
   for (int64_t c = 0; c < o->nc; ++c) {
     const int64_t cw = (int64_t)get_u32(q + 4 * c);
-    PCC_REQUIRE(cw >= 2 * kLanes, PCC_E_STREAM, "octree blob v2: chunk %lld has no states", (long long)c);
+    PCC_REQUIRE(cw >= 3 * kLanes, PCC_E_STREAM, "octree blob v2: chunk %lld has no states", (long long)c);
     words += cw;
   }
   o->off_payload = o->off_table + 4 * o->nc;

@@ -707,9 +707,9 @@ ORC_API int64_t orc_octree_encode(const int32_t* points, int64_t n, int bias, ui
  *   chunk c, lane l: nodes [(64 c + l) S, (64 c + l + 1) S) below n_nodes = sum(level_n)
  *   step t = 8 s + j of a chunk: every lane codes bit j of its node s (nothing when the node does not exist or the
  *   bit is implied: j == 7 after seven zeros)
- *   payload = 64 x (state lo, state hi) | block(step 0) | block(step 1) ..: a block holds the 16-bit words the
- *   decoder's lanes need after that step, in ascending lane order.
- * The encoder walks the steps backwards, lanes in descending order, and fills the chunk from its end. */
+ *   payload = 64 x (state lo, state hi) | u16 len[64] | words of lane 0 | words of lane 1 | ..: every lane has its
+ *   own run of 16-bit renormalisation words, in the order its decoder consumes them (len[l] of them).
+ * The encoder walks a lane's steps backwards and reverses the words it emitted. */
 #define O2_LANES 64
 #define O2_SMAX 512
 #define O2_CTX 108
@@ -793,7 +793,7 @@ ORC_API int64_t orc_octree2_encode(const int32_t* points, int64_t n, int bias, u
   for (int i = 0; i < O2_CTX; ++i, q += 2) { q[0] = (uint8_t)p0[i]; q[1] = (uint8_t)(p0[i] >> 8); }
   uint8_t* table = q;
   int64_t pos = head;
-  const int64_t T = 8 * S, cw_cap = 2 * O2_LANES + O2_LANES * T;
+  const int64_t T = 8 * S, cw_cap = 3 * O2_LANES + O2_LANES * T;
   uint16_t* buf = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cw_cap);
   uint16_t* rec = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)(O2_LANES * T));   /* [t][lane]: p | bit << 15, 0 = nothing coded */
   int64_t ret = 0;
@@ -817,24 +817,28 @@ ORC_API int64_t orc_octree2_encode(const int32_t* points, int64_t n, int bias, u
         }
       }
     }
+    /* per lane: the rANS steps in reverse; the words come out last-consumed first and are stored reversed */
     uint32_t x[O2_LANES];
-    for (int l = 0; l < O2_LANES; ++l) x[l] = 1u << 16;
-    int64_t ptr = cw_cap;
-    for (int64_t t = T - 1; t >= 0; --t)
-      for (int l = O2_LANES - 1; l >= 0; --l) {
+    int64_t ptr = 3 * O2_LANES;          /* words behind the states and the length table */
+    for (int l = 0; l < O2_LANES; ++l) {
+      x[l] = 1u << 16;
+      const int64_t first = ptr;
+      for (int64_t t = T - 1; t >= 0; --t) {
         const uint16_t r = rec[t * O2_LANES + l];
         if (!r) continue;
         const uint32_t p1 = r & 0xFFFu, bit = r >> 15;
         const uint32_t freq = bit ? p1 : 4096 - p1, start = bit ? 4096 - p1 : 0;
-        if ((uint64_t)x[l] >= ((uint64_t)freq << 20)) { buf[--ptr] = (uint16_t)x[l]; x[l] >>= 16; }
+        if ((uint64_t)x[l] >= ((uint64_t)freq << 20)) { buf[ptr++] = (uint16_t)x[l]; x[l] >>= 16; }
         x[l] = ((x[l] / freq) << 12) + (x[l] % freq) + start;
       }
-    ptr -= 2 * O2_LANES;
-    for (int l = 0; l < O2_LANES; ++l) { buf[ptr + 2 * l] = (uint16_t)x[l]; buf[ptr + 2 * l + 1] = (uint16_t)(x[l] >> 16); }
-    const int64_t cw = cw_cap - ptr;
+      for (int64_t a = first, b = ptr - 1; a < b; ++a, --b) { const uint16_t tmp = buf[a]; buf[a] = buf[b]; buf[b] = tmp; }
+      buf[2 * O2_LANES + l] = (uint16_t)(ptr - first);
+    }
+    for (int l = 0; l < O2_LANES; ++l) { buf[2 * l] = (uint16_t)x[l]; buf[2 * l + 1] = (uint16_t)(x[l] >> 16); }
+    const int64_t cw = ptr;
     if (pos + 2 * cw > cap) { ret = -1; break; }
     w32(table + 4 * c, (uint32_t)cw);
-    for (int64_t k = 0; k < cw; ++k) { out[pos + 2 * k] = (uint8_t)buf[ptr + k]; out[pos + 2 * k + 1] = (uint8_t)(buf[ptr + k] >> 8); }
+    for (int64_t k = 0; k < cw; ++k) { out[pos + 2 * k] = (uint8_t)buf[k]; out[pos + 2 * k + 1] = (uint8_t)(buf[k] >> 8); }
     pos += 2 * cw;
   }
   free(rec); free(buf); free(occ);
@@ -867,14 +871,19 @@ static int64_t o2_decode_bytes(const uint8_t* in, int64_t len, uint8_t** occ_out
   int bad = 0;
   for (int64_t c = 0; c < nc && !bad; ++c) {
     const int64_t cw = (int64_t)r32(table + 4 * c);
-    if (cw < 2 * O2_LANES || end - pl < 2 * cw) { bad = 1; break; }
+    if (cw < 3 * O2_LANES || end - pl < 2 * cw) { bad = 1; break; }
     uint32_t x[O2_LANES];
     int ones[O2_LANES];
+    int64_t lp[O2_LANES], le[O2_LANES];   /* next word / end of every lane's run */
+    int64_t run = 3 * O2_LANES;
     for (int l = 0; l < O2_LANES; ++l) {
       x[l] = (uint32_t)(pl[4 * l] | (pl[4 * l + 1] << 8)) | ((uint32_t)(pl[4 * l + 2] | (pl[4 * l + 3] << 8)) << 16);
       memcpy(model + l * O2_CTX, p0, sizeof p0);
+      lp[l] = run;
+      run += (int64_t)(pl[4 * O2_LANES + 2 * l] | (pl[4 * O2_LANES + 2 * l + 1] << 8));
+      le[l] = run;
     }
-    int64_t ptr = 2 * O2_LANES;
+    if (run != cw) { bad = 1; break; }
     for (int64_t t = 0; t < 8 * S && !bad; ++t) {
       const int64_t s = t >> 3; const int j = (int)(t & 7);
       for (int l = 0; l < O2_LANES; ++l) {
@@ -890,16 +899,16 @@ static int64_t o2_decode_bytes(const uint8_t* in, int64_t len, uint8_t** occ_out
           const uint32_t start = bit ? 4096 - p1 : 0, freq = bit ? p1 : 4096 - p1;
           x[l] = freq * (x[l] >> 12) + cum - start;
           if (x[l] < (1u << 16)) {
-            if (ptr >= cw) { bad = 1; break; }
-            x[l] = (x[l] << 16) | (uint32_t)(pl[2 * ptr] | (pl[2 * ptr + 1] << 8));
-            ++ptr;
+            if (lp[l] >= le[l]) { bad = 1; break; }
+            x[l] = (x[l] << 16) | (uint32_t)(pl[2 * lp[l]] | (pl[2 * lp[l] + 1] << 8));
+            ++lp[l];
           }
           oct_adapt(m, bit);
         }
         if (bit) { occ[node] |= (uint8_t)(1u << j); ones[l]++; }
       }
     }
-    if (ptr != cw) bad = 1;
+    for (int l = 0; l < O2_LANES; ++l) if (lp[l] != le[l]) bad = 1;   /* every word consumed */
     pl += 2 * cw;
   }
   free(model);

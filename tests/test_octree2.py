@@ -43,7 +43,7 @@ def _occupancy_bytes(pts):
 
 
 def py_octree2_encode(points, bias):
-    """blob version 2, written from the description in csrc/octree2.hip's header: per-lane lists instead of the
+    """blob version 2, written from the description in csrc/octree2.hip's header: per-step lists instead of the
     oracle's [step][lane] record table, Python integers throughout"""
     pts = np.unique(np.asarray(points, dtype=np.int64) + bias, axis=0)
     n = pts.shape[0]
@@ -86,18 +86,18 @@ def py_octree2_encode(points, bias):
                     per_step.setdefault(8 * s + j, []).append((l, model[ctx], bit))
                     model[ctx] = model[ctx] + ((4096 - model[ctx]) >> 4) if bit else model[ctx] - (model[ctx] >> 4)
         x = [1 << 16] * LANES
-        words = []                                # in emission order (reversed at the end)
+        words = [[] for _ in range(LANES)]        # per lane, in emission order (reversed below)
         for t in sorted(per_step, reverse=True):
-            for l, p1, bit in sorted(per_step[t], reverse=True):
+            for l, p1, bit in per_step[t]:
                 freq, start = (p1, 4096 - p1) if bit else (4096 - p1, 0)
                 if x[l] >= freq << 20:
-                    words.append(x[l] & 0xFFFF)
+                    words[l].append(x[l] & 0xFFFF)
                     x[l] >>= 16
                 x[l] = ((x[l] // freq) << 12) + x[l] % freq + start
         states = []
         for l in range(LANES):
             states += [x[l] & 0xFFFF, x[l] >> 16]
-        chunks.append(states + words[::-1])
+        chunks.append(states + [len(w) for w in words] + [v for w in words for v in w[::-1]])
     body = b"".join(struct.pack("<I", len(lv)) for lv in levels) + struct.pack("<II", S, nc)
     body += struct.pack("<%dH" % CTX, *p0) + b"".join(struct.pack("<I", len(ch)) for ch in chunks)
     body += b"".join(struct.pack("<%dH" % len(ch), *ch) for ch in chunks)
@@ -140,15 +140,16 @@ def test_v2_known_answer_one_point(oracle):
       ctx 15 bit 1: freq 3072, start 1024: x = (115712 // 3072 << 12) + 115712 % 3072 + 1024 = 37*4096 + 2048 + 1024 = 154624
       ctx 10, 6, 3, 1, 0 bit 0 (freq 3072 each): 154624 -> 50*4096 + 1024 = 205824 -> 67*4096 + 0 = 274432
                                                  -> 89*4096 + 1024 = 365568 -> 119*4096 + 0 = 487424 -> 158*4096 + 2048 = 649216
-    never reaches freq << 20, so no word is emitted: lane 0's state = 649216 = 0x0009E800, the other 63 lanes 0x00010000."""
+    never reaches freq << 20, so no word is emitted: lane 0's state = 649216 = 0x0009E800, the other 63 lanes 0x00010000,
+    and every lane's run of words has length 0: the chunk is 128 state words + 64 lengths = 192 words."""
     blob = oracle.octree_encode(np.array([[3, -4, 5]], np.int32), 32768, version=2)
     p0 = [2048] * CTX
     for k in (0, 1, 3, 6, 10, 22, 29):
         p0[k] = 1024
     p0[15] = 3072
     states = [0xE800, 0x0009] + [0x0000, 0x0001] * 63
-    body = struct.pack("<I", 1) + struct.pack("<II", 4, 1) + struct.pack("<108H", *p0) + struct.pack("<I", 128)
-    body += struct.pack("<128H", *states)
+    body = struct.pack("<I", 1) + struct.pack("<II", 4, 1) + struct.pack("<108H", *p0) + struct.pack("<I", 192)
+    body += struct.pack("<128H", *states) + struct.pack("<64H", *([0] * 64))
     want = bytes([ord("O"), 2, 1, 0]) + struct.pack("<I", 1) + struct.pack("<3i", 2, -4, 4) + struct.pack("<I", len(body)) + body
     assert blob == want
     assert np.array_equal(oracle.octree_decode(blob), [[3, -4, 5]])
@@ -180,11 +181,19 @@ def test_oracle_v2_rejects_corrupt_blobs(oracle):
                                             C.c_int64(n))
     assert decode(blob) == n
     depth = blob[2]
-    for off in (24, 24 + 4 * (depth - 1), 24 + 4 * depth, 24 + 4 * depth + 4, 24 + 4 * depth + 8, 24 + 4 * depth + 8 + 216,
-                len(blob) - 1, len(blob) - 300):
-        bad = bytearray(blob)
+    head = 24 + 4 * depth + 8 + 216
+    for off in (24, 24 + 4 * (depth - 1), 24 + 4 * depth, 24 + 4 * depth + 4, 24 + 4 * depth + 8, head, head + 4 + 2 * 128 + 5):
+        bad = bytearray(blob)                       # level sizes, S, chunk count, p0, chunk table, a lane's word count
         bad[off] ^= 0x40
         assert decode(bad) == -1, off
+    errors = 0
+    for off in range(len(blob) - 900, len(blob), 11):   # renormalisation words: an error, or (a flip that leaves the child
+        bad = bytearray(blob)                           # counts alone) another set of the same size — never a crash
+        bad[off] ^= 0x40
+        rc = decode(bad)
+        assert rc in (-1, n), off
+        errors += rc == -1
+    assert errors > 40
     assert decode(blob[:-2]) == -1
 
 

@@ -8,11 +8,12 @@ R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-psnr --inflight 0"
+B="python3 $R/bench.py --no-cpu-baseline --no-psnr --inflight 0 --no-configs"
 echo "== kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_stats -- $B --steps 10 --warmup 3 > $O/${P}_stats.log 2>&1 || exit 1
 cp $(ls $O/${P}_stats/*/*_kernel_stats.csv | head -1) $O/${P}_bench_kernel_stats.csv
 grep '^{' $O/${P}_stats.log | tail -1 > $O/${P}_bench_line.json
+python3 $R/tools/launches_by_grid.py $O/${P}_stats $O/${P}_launches_by_grid.json "kernel trace of the ${P} stats run (bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-psnr --inflight 0 --no-configs) grouped by kernel and grid size; durations in microseconds" > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== $c"
   rm -rf $O/pmc_$c
@@ -30,3 +31,8 @@ done
 python3 $R/tools/pmc_sq.py $O/${P}_sq "k_gconv_up<true>" > $O/${P}_pmc_sq_conv.json
 cat $O/${P}_pmc_sq_conv.json | head -40
 cat $O/${P}_bench_line.json | cut -c1-400
+# the geometry-only configuration (BASELINE.json configs[2]): kernels of blob version 2 (octree2.hip)
+echo "== C3 kernel stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${P}_c3 -- python3 $R/tools/bench_c3.py > $O/${P}_c3.log 2>&1 || exit 1
+cp $(ls $O/${P}_c3/*/*_kernel_stats.csv | head -1) $O/${P}_c3_kernel_stats.csv
+python3 $R/tools/launches_by_grid.py $O/${P}_c3 $O/${P}_c3_launches_by_grid.json "kernel trace of tools/bench_c3.py (sweep + 1M-point room, blob versions 1 and 2)" > /dev/null
