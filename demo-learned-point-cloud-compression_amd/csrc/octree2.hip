@@ -58,7 +58,11 @@ __host__ __device__ inline uint32_t o2_p0(uint64_t c0, uint64_t c1) {
   const uint64_t p = (4096ull * (2 * c1 + 1)) / (2 * (c0 + c1 + 1));
   return (uint32_t)(p < 16 ? 16 : (p > 4080 ? 4080 : p));
 }
-__device__ __forceinline__ uint32_t o2_adapt(uint32_t p, uint32_t bit) { return bit ? p + ((4096u - p) >> 4) : p - (p >> 4); }
+// (both sides computed and merged by a mask: written as a conditional expression the compiler made it a divergent branch)
+__device__ __forceinline__ uint32_t o2_adapt(uint32_t p, uint32_t bit) {
+  const uint32_t up = p + ((4096u - p) >> 4), dn = p - (p >> 4), m = 0u - bit;
+  return (up & m) | (dn & ~m);
+}
 __device__ __forceinline__ int lane_rank(unsigned long long bal) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
 }
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
                                                uint16_t* __restrict__ rec, uint16_t* __restrict__ work,
                                                uint16_t* __restrict__ states, uint16_t* __restrict__ lens,
                                                uint32_t* __restrict__ words_out, uint16_t* __restrict__ p0_out) {
-  __shared__ uint16_t s_model[kCtx * kLanes];   // [ctx][lane]
+  __shared__ uint16_t s_model[(kCtx + 1) * kLanes];   // [ctx][lane]; row kCtx takes the writes of decisions that are not coded
   __shared__ uint16_t s_p0[kCtx];
   __shared__ __attribute__((aligned(16))) uint32_t s_rcp[4096];
   const int lane = threadIdx.x;
@@ -146,7 +150,11 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
   __syncthreads();
   for (int ctx = 0; ctx < kCtx; ++ctx) s_model[ctx * kLanes + lane] = s_p0[ctx];
   const int64_t T = 8 * (int64_t)S;
-  uint16_t* recw = rec + c * T * kLanes;
+  // records: one 16-byte piece per (node, lane) — the node's 8 decisions —, [chunk][node][lane]: the forward pass stores
+  // one dwordx4 per node, the backward pass requests a node's piece four nodes (32 steps) ahead.  (As [step][lane]
+  // 16-bit entries requested 8 steps ahead the backward pass waited for every one of them: a step is ~0.1 us, a load
+  // that comes from L2 ~0.8 us.)
+  uint4* rec4 = reinterpret_cast<uint4*>(rec) + c * (int64_t)S * kLanes;
   const int64_t node0 = (c * kLanes + lane) * S;   // a multiple of 4: four nodes per dword
   const int64_t last_dw = (n_nodes - 1) >> 2;
   uint32_t dw_next = occ32[(node0 >> 2) < last_dw ? (node0 >> 2) : last_dw];
@@ -166,13 +174,15 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
         at[j] = (cls * 36 + j * (j + 1) / 2 + __popc(byte & ((1u << j) - 1u))) * kLanes + lane;
         p[j] = s_model[at[j]];
       }
+      uint32_t r[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t bit = (byte >> j) & 1u;
         const bool act = valid && !(j == 7 && (byte & 0x7Fu) == 0u);
-        recw[((int64_t)(s + q) * 8 + j) * kLanes + lane] = act ? (uint16_t)(p[j] | (bit << 15)) : (uint16_t)0;
-        if (act) s_model[at[j]] = (uint16_t)o2_adapt(p[j], bit);
+        r[j] = act ? (p[j] | (bit << 15)) : 0u;
+        s_model[act ? at[j] : kCtx * kLanes + lane] = (uint16_t)o2_adapt(p[j], bit);   // no branch: a dummy row for the rest
       }
+      rec4[(int64_t)(s + q) * kLanes + lane] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
     }
   }
 
@@ -182,11 +192,11 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
   int wp = (int)T;            // words [wp, T) of the lane's region are written
   const uint32_t lane_off = (uint32_t)lane * (uint32_t)T * 2u;
   uint32_t x = kL;
-  constexpr int kAhead = 8;   // T is a multiple of 8
-  uint32_t r_q[kAhead];
-  auto fetch = [&](int64_t t) -> uint32_t { return recw[(t >= 0 ? t : 0) * kLanes + lane]; };
+  constexpr int kAhead = 4;   // nodes in flight (S is a multiple of 4)
+  uint4 R[kAhead];
+  auto fetch = [&](int sn) -> uint4 { return rec4[(int64_t)(sn >= 0 ? sn : 0) * kLanes + lane]; };
 #pragma unroll
-  for (int d = 0; d < kAhead; ++d) r_q[d] = fetch(T - 1 - d);
+  for (int d = 0; d < kAhead; ++d) R[d] = fetch(S - 1 - d);
   struct Prep {
     uint32_t freq, start, rcp;
     bool act;
@@ -200,25 +210,36 @@ __global__ __launch_bounds__(64) void k_o2_enc(const uint32_t* __restrict__ occ3
     q.rcp = s_rcp[q.freq & 4095u];
     return q;
   };
-  Prep cur = prep(r_q[0]);
-  for (int64_t t0 = T - 1; t0 >= 0; t0 -= kAhead) {
+  auto rec_of = [](const uint4& v, int j) -> uint32_t {
+    const uint32_t w = j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w));
+    return (w >> (16 * (j & 1))) & 0xFFFFu;
+  };
+  Prep cur = prep(rec_of(R[0], 7));
+  for (int s0 = S - 1; s0 >= 0; s0 -= kAhead) {
 #pragma unroll
     for (int d = 0; d < kAhead; ++d) {
-      const int64_t t = t0 - d;
-      r_q[d] = fetch(t - kAhead);
-      const Prep nxt = prep(t > 0 ? r_q[(d + 1) % kAhead] : 0u);
-      const bool need = cur.act && x >= (cur.freq << 20);   // ((L >> 12) << 16) * freq; freq <= 4081
-      wp -= need ? 1 : 0;
-      __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x, reg_rs, need ? lane_off + (uint32_t)wp * 2u : 0xFFFFFFF0u, 0, 0);
-      if (need) x >>= 16;
-      if (cur.act) {
-        // x / freq with x < 2^20 freq: mulhi by floor(2^32 / freq) is the quotient or one less
-        uint32_t qd = __umulhi(x, cur.rcp);
-        uint32_t rem = x - qd * cur.freq;
-        if (rem >= cur.freq) { ++qd; rem -= cur.freq; }
-        x = (qd << 12) + rem + cur.start;
+      const int sn = s0 - d;
+      const uint4 Rc = R[d];
+      const uint4 Rn = R[(d + 1) % kAhead];   // node sn - 1 (requested earlier; for d == kAhead - 1: at the top of this round)
+#pragma unroll
+      for (int j = 7; j >= 0; --j) {
+        const Prep nxt = j > 0 ? prep(rec_of(Rc, j - 1)) : prep(sn > 0 ? rec_of(Rn, 7) : 0u);
+        const bool need = cur.act && x >= (cur.freq << 20);   // ((L >> 12) << 16) * freq; freq <= 4081
+        wp -= need ? 1 : 0;
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)x, reg_rs, need ? lane_off + (uint32_t)wp * 2u : 0xFFFFFFF0u, 0, 0);
+        x = need ? x >> 16 : x;
+        {
+          // x / freq with x < 2^20 freq: mulhi by floor(2^32 / freq) is the quotient or one less.  Selects, no branch: a
+          // divergent branch costs a lone wave more than the six instructions it would skip
+          const uint32_t q0 = __umulhi(x, cur.rcp);
+          const uint32_t r0 = x - q0 * cur.freq;
+          const bool over = r0 >= cur.freq;
+          const uint32_t qd = q0 + (over ? 1u : 0u), rem = r0 - (over ? cur.freq : 0u);
+          x = cur.act ? (qd << 12) + rem + cur.start : x;
+        }
+        cur = nxt;
       }
-      cur = nxt;
+      R[d] = fetch(sn - kAhead);   // the slot is free: node sn - kAhead into it
     }
   }
   states[c * 2 * kLanes + 2 * lane] = (uint16_t)x;
@@ -318,7 +339,7 @@ struct O2Offs {
 
 // the chunk's words in LDS when they fit (a chunk is 64 S nodes: <= 32 KB of payload for S = 512 unless the stream was
 // made to cost more than 8 bits per node), else read from the stream where they lie (slow, correct)
-constexpr int kDecLdsWords = 24576;   // 48 KB beside the 13.8 KB of models
+constexpr int kDecLdsWords = 24576;   // 48 KB beside the 13.9 KB of models
 
 template <bool IN_LDS>
 __device__ __forceinline__ void o2_decode_chunk(uint16_t* s_model, const uint16_t* __restrict__ s_words,
@@ -357,6 +378,7 @@ __device__ __forceinline__ void o2_decode_chunk(uint16_t* s_model, const uint16_
   // the model entry of the NEXT decision is requested before the current one is decoded — both candidates (the ones
   // so far, and one more) — so that the LDS round trip is not on the chain from state to state
   uint32_t p_cur = s_model[(cls_of(node0) * 36) * kLanes + lane];
+  const int a_dummy = kCtx * kLanes + lane;   // takes the model writes of decisions that are not coded (no branch)
   for (int s = 0; s < S; s += 4) {
     uint32_t dw = 0;
 #pragma unroll
@@ -380,26 +402,22 @@ __device__ __forceinline__ void o2_decode_chunk(uint16_t* s_model, const uint16_
         const bool act = valid && !(j == 7 && ones == 0);
         const uint32_t p1 = p_cur;
         const uint32_t cum = x & 4095u;
-        uint32_t bit = cum >= 4096u - p1 ? 1u : 0u;
-        const uint32_t start = bit ? 4096u - p1 : 0u, freq = bit ? p1 : 4096u - p1;
-        if (act) {
-          x = freq * (x >> 12) + cum - start;
-          s_model[at] = (uint16_t)o2_adapt(p1, bit);
-        } else {
-          bit = valid ? 1u : 0u;   // the implied bit
-        }
+        const uint32_t dbit = cum >= 4096u - p1 ? 1u : 0u;
+        const uint32_t start = dbit ? 4096u - p1 : 0u, freq = dbit ? p1 : 4096u - p1;
+        const uint32_t xn = freq * (x >> 12) + cum - start;
+        x = act ? xn : x;
+        s_model[act ? at : a_dummy] = (uint16_t)o2_adapt(p1, dbit);
+        const uint32_t bit = act ? dbit : (valid ? 1u : 0u);   // else: the implied bit
         const bool need = act && x < kL;
-        if (need) {
-          if (pos >= rend) bad |= 1;
-          x = (x << 16) | nextw;
-          ++pos;
-          nextw = word_at(pos);
-        }
+        bad |= (need && pos >= rend) ? 1 : 0;
+        x = need ? (x << 16) | nextw : x;
+        pos += need ? 1u : 0u;
+        nextw = word_at(pos);   // every step (the same word again when nothing was consumed): no branch
         ones += (int)bit;
         byte |= bit << j;
         p_cur = (j < 7 && bit) ? c1 : c0;
       }
-      if (valid && byte == 0u) bad |= 2;
+      bad |= (valid && byte == 0u) ? 2 : 0;
       dw |= byte << (8 * q);
     }
     __builtin_amdgcn_raw_buffer_store_b32(dw, occ_rs, (uint32_t)(node0 + s), 0, 0);
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(64) void k_o2_dec(const uint16_t* __restrict__ p0, 
                                                const uint16_t* __restrict__ payload, int64_t n_nodes, int64_t start_last,
                                                int64_t start_prev, int S, uint32_t* __restrict__ occ32,
                                                int32_t* __restrict__ status) {
-  __shared__ uint16_t s_model[kCtx * kLanes];
+  __shared__ uint16_t s_model[(kCtx + 1) * kLanes];   // row kCtx: dummy (o2_decode_chunk)
   __shared__ __attribute__((aligned(16))) uint16_t s_words[kDecLdsWords];
   const int lane = threadIdx.x;
   const int64_t c = blockIdx.x;
