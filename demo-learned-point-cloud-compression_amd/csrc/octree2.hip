@@ -22,11 +22,13 @@
 // step: a lone wave issues one instruction every ~5 cycles whether or not it depends on the one before, and a step was
 // ~100 instructions — the refill's ballot, two ds_bpermute and window bookkeeping, a 64-bit-float division per
 // decision in the encoder.  Per-lane runs need none of that: a refill is a shift and an LDS read of the lane's own next
-// word, the division a lookup of 2^32 / freq in a 16-KB LDS table; 128 B of length table per chunk: +0.9 % bytes.)
+// word, the division a lookup of 2^32 / freq in a 16-KB LDS table; 128 B of length table per chunk: +0.9 % bytes.
+// With steps free of divergent branches and the encoder's records as 16-byte pieces per node: 0.53 / 0.52 ms to code /
+// decode the sweep, blob on the host <-> keys / points in HBM; DESIGN.md 6c has the steps.)
 //
 // A lane's model starts from the frame's average probability per context (p0: a counting pass, 216 B of header)
-// instead of 1/2, so that a run of 512 nodes does not pay for learning it again: +2.7 % bytes against version 1 on
-// the sweep (of which 1.5 % are the 4-byte final states), +2 % on a 300k-point room.  The node count of every level
+// instead of 1/2, so that a run of 512 nodes does not pay for learning it again: +3.6 % bytes against version 1 on
+// the sweep (1.5 % the 4-byte final states, 0.9 % the run lengths), +4.3 % on a 1M-point room.  The node count of every level
 // is in the header because a decoder lane needs the level class of a node before the levels above it are decoded;
 // with them ALL nodes decode in one launch, and the leaves follow from ONE exclusive scan of the nodes' child counts
 // (breadth-first numbering: the first child of node i is node 1 + sum of the child counts in front of i), a pass that
