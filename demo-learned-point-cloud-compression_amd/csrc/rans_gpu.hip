@@ -243,34 +243,34 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
     int32_t start, freq, nb;
     uint32_t raw;
     bool esc, act;
-    double rinv;
+    float rinv;
   };
+  // Without a branch (round 4): a lone wave pays for the NUMBER of instructions it issues, and a divergent branch costs it
+  // more than the handful it would skip (octree2.hip has the measurements).  The lanes of a step that codes nothing run
+  // the same instructions on the first symbol's values and are masked where the state is updated.
   auto prep = [&](int64_t t, int32_t sv, int r) -> Prep {
-    Prep p{0, 1, 0, 0u, false, false, 1.0};
+    Prep p;
     const int64_t i = base + t * kLanes + lane;
     p.act = t >= 0 && i < n;
-    if (p.act) {
-      if constexpr (HAS_IDX) r = (int)(((uint32_t)r >> (8 * (int)((i + sidx_mis) & 3))) & 0xFFu);
-      r = r < tv.n_cdf ? r : tv.n_cdf - 1;   // a table index out of range never reaches the LDS tables (the entry points check what they can)
-      const int off = s_row[3 * r], len = s_row[3 * r + 1];
-      const int32_t max_value = len - 2;
-      int32_t v = sv - s_row[3 * r + 2];
-      if (v < 0) {
-        p.raw = (uint32_t)(-2 * (int64_t)v - 1);
-        v = max_value;
-      } else if (v >= max_value) {
-        p.raw = (uint32_t)(2 * ((int64_t)v - max_value));
-        v = max_value;
-      }
-      p.esc = v == max_value;
-      if (p.esc)
-        while (p.nb < 8 && (p.raw >> (4 * p.nb)) != 0) ++p.nb;
-      const uint32_t c0 = s_cdf[off + v], c1 = s_cdf[off + v + 1];
-      p.start = (int32_t)c0;
-      p.freq = (int32_t)((c1 - c0) & 0xFFFFu);
-      if (p.freq == 0) p.freq = 65536;
-      p.rinv = 1.0 / (double)p.freq;
-    }
+    if constexpr (HAS_IDX) r = (int)(((uint32_t)r >> (8 * (int)((i + sidx_mis) & 3))) & 0xFFu);
+    r = p.act ? r : 0;
+    r = r < tv.n_cdf ? r : tv.n_cdf - 1;   // a table index out of range never reaches the LDS tables (the entry points check what they can)
+    const int off = s_row[3 * r], len = s_row[3 * r + 1];
+    const int32_t max_value = len - 2;
+    const int32_t v0 = sv - s_row[3 * r + 2];
+    const bool neg = v0 < 0, big = v0 >= max_value;
+    p.raw = neg ? (uint32_t)(-2 * (int64_t)v0 - 1) : (big ? (uint32_t)(2 * ((int64_t)v0 - max_value)) : 0u);
+    p.esc = p.act && (neg || big);            // (v0 == max_value is `big` with raw 0: the escape bin followed by a count of 0)
+    const int32_t v = (neg || big) ? max_value : v0;
+    p.nb = p.raw ? (35 - __clz((int)p.raw)) >> 2 : 0;   // 4-bit nibbles of raw: at most 8
+    const uint32_t c0 = s_cdf[off + v], c1 = s_cdf[off + v + 1];
+    p.start = (int32_t)c0;
+    const int32_t f = (int32_t)((c1 - c0) & 0xFFFFu);
+    p.freq = f == 0 ? 65536 : f;
+    // 1 / freq in single precision is enough for a quotient below 2^16 that the remainder corrects by one (the relative
+    // errors of (float)x, of v_rcp_f32 and of the product add up to ~2^-22: 2^-6 of a unit of the quotient) — the
+    // double-precision division this replaces was 16 of a step's instructions
+    p.rinv = __frcp_rn((float)p.freq);
     return p;
   };
   Prep cur = prep(T - 1, sv_q[0], rv_q[0]);
@@ -303,17 +303,16 @@ __global__ __launch_bounds__(256) void k_rans_enc(RansView tv, const int32_t* __
     {  // round 0: the symbol's bin
       const bool need = act && (uint64_t)x >= ((uint64_t)(uint32_t)freq << 16);   // ((L >> 16) << 16) * freq (freq may be 2^16)
       emit(need);
-      if (need) x >>= 16;
-      if (act) {
-        // x / freq, x % freq with x < 2^16 freq: the quotient from one multiplication by 1 / freq in double (exact operands,
-        // quotient below 2^16: off by at most one), corrected by the remainder — no division on the chain from state to state
-        const uint32_t f = (uint32_t)freq;
-        uint32_t qd = (uint32_t)((double)x * cur.rinv);
-        int64_t rem = (int64_t)x - (int64_t)qd * f;
-        if (rem < 0) { --qd; rem += (int64_t)f; }
-        else if (rem >= (int64_t)f) { ++qd; rem -= (int64_t)f; }
-        x = (qd << 16) + (uint32_t)rem + (uint32_t)start;
-      }
+      x = need ? x >> 16 : x;
+      // x / freq, x % freq with x < 2^16 freq: the quotient from one multiplication by 1 / freq (quotient below 2^16: off by
+      // at most one either way), corrected by the remainder — no division on the chain from state to state, no branch
+      const uint32_t f = (uint32_t)freq;
+      const uint32_t q0 = (uint32_t)((float)x * cur.rinv);
+      const int32_t r0 = (int32_t)(x - q0 * f);                  // in (-f, 2f): fits 32 bits (f <= 2^16)
+      const bool under = r0 < 0, over = r0 >= (int32_t)f;
+      const uint32_t qd = q0 - (under ? 1u : 0u) + (over ? 1u : 0u);
+      const uint32_t rem = (uint32_t)(r0 + (under ? (int32_t)f : 0) - (over ? (int32_t)f : 0));
+      x = act ? (qd << 16) + rem + (uint32_t)start : x;
     }
     cur = nxt;
    }
@@ -441,8 +440,8 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
     const uint32_t dw = at < 64 ? wa : wbv;
     const uint32_t w = (dw >> (16 * ((at + mis) & 1))) & 0xFFFFu;   // wb is even: the parity of word wb + at is that of at
     const bool fits = ptr + cnt <= (int64_t)cw;
-    if (!fits && cnt) bad |= 1;
-    if (need) x = fits ? (x << 16) | w : kL;   // out of words: keep the arithmetic defined; the status word reports the stream
+    bad |= (!fits && cnt) ? 1 : 0;
+    x = need ? (fits ? (x << 16) | w : kL) : x;   // out of words: keep the arithmetic defined; the status word reports the stream
     ptr += fits ? cnt : 0;
     const bool cross = ptr - wb >= 64;   // wave-uniform
     wb += cross ? 64 : 0;
@@ -482,6 +481,8 @@ __global__ __launch_bounds__(256) void k_rans_dec(RansView tv, const uint32_t* _
     r_q[d] = fetch_idx(t + kDecAhead);
     int32_t value = 0, max_value = 0, off_sym = 0;
     bool esc = false;
+    // (round 4: this block as selects under a wave-uniform search loop, like the encoder's step, measured 174 us against
+    // 169 — the decoder's step is the chain of dependent LDS reads of the search, not its instruction count)
     if (act) {
       if constexpr (HAS_IDX) r = (int)(((uint32_t)r >> (8 * (int)((i + idx_mis) & 3))) & 0xFFu);
       if (r >= tv.n_cdf) {   // reported through the status word; the tables are read at the last row instead
