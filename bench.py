@@ -428,7 +428,7 @@ def main():
                     "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
                     "note": "one wave per chunk of 64 x steps symbols, steps coded one after the other: the launch "
-                            "lasts as long as ONE chunk (latency of a dependent 64-bit state update and a binary search "
+                            "lasts as long as ONE chunk (latency of a dependent 32-bit state update and a binary search "
                             "in LDS per step), far from the HBM roof by construction; what it buys is the removal of the "
                             "serial host coder and of the symbols' PCIe round trip"}
     # the reference's container + seek-point trailer (pcc_codec_set_seek_points): everything the reference's reader reads

@@ -3,14 +3,15 @@ frames compared with the CPU oracle AT FULL SIZE (the oracle codes a 1M-point fr
 size-independent properties.
 
   C2  1M-point ScanNet-scale frame, hyperprior model  — bytes + reconstruction = oracle; round trip, container structure
-  C3  ~120k-point LiDAR sweep, geometry-only octree   — lossless, equals the oracle's blob
+  C3  ~100k-point LiDAR sweep, geometry-only octree   — lossless, equals the oracle's blob (blob version 2: coded and decoded by the GPU)
   C4  ~800k-point dense body with RGB                 — bytes + reconstruction = oracle; round trip
   C5  4M-point scan in 8 tiles                        — tests/test_gpu_tiled.py
   multi-frame GOP with empty-ish and tiny frames      — per-frame bookkeeping
 
-The full-size comparisons are the only ones that run the large-layer kernels where they ship: the four-windows-per-
-workgroup conv on 3.26M candidate rows (int32 row arithmetic (pr << 3) | o, several rounds of XCD windows, grid
-round-up past the last row), the radix sort on 1M keys, top-k over millions of logits.
+The full-size comparisons are the only ones that run the large-layer kernels where they ship: k_gconv_up on 3.26M
+candidate rows (one wave per 128-row window, windows taken from the end of the tensor, twelve rounds of resident waves,
+grid round-up past the last row), the persistent-wave up stage k_convT16p, the radix sort on 1M keys, top-k over
+millions of logits, and (the 3M-point frame) a latent above 65536 leaves: geometry blob version 2 inside the codec.
 (reference: sender/encoder/codec_pipeline.py:196-236, receiver/decoder/codec_parallel.py:141-171)
 """
 import struct
