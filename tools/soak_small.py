@@ -25,7 +25,7 @@ def main():
             [wl.sphere_shell(40, 15.0, seed=5, offset=(3, -70, 11)), wl.body(20000, seed=3)], [wl.room(120_000, seed=4)]]
     refs = []
     for g in gops:
-        ref, _ = oracle.compress(g, S, version=version)
+        ref, _ = oracle.compress(g, S, version=version, seek_points=int(os.environ.get("PCC_SEEK_POINTS", "0")))   # the pipeline reads the same variable
         refs.append((ref, {q: oracle.decompress(ref[q]) for q in (1, 2, 3)}))
     enc = pkg.CompressionPipeline(S, device=0, slots=1, container_version=version)
     dec = pkg.DecompressionPipeline(device=0, slots=1)
