@@ -255,6 +255,14 @@ struct pcc_codec {
   // The reference's reader stops at the last frame record (codec_parallel.py:200-213) and never sees it; this library's
   // decoder decodes the pieces between the points on as many host threads.
   int seek_points = 0;
+  // scale_nn(q) + eps rows on the device, kept while the same quality settings come in (every call of a service): two
+  // slots, the encoder's Q rows and the decoder's one row.  (A per-call upload from a std::vector is a staged copy of
+  // pageable memory: ~10 us of the calling thread and a launch on the stream for 128 bytes.)
+  struct ScaleSlot {
+    std::vector<double> key;
+    float* dev = nullptr;
+    size_t cap = 0;
+  } scale_slot[2];
   pcc_rans_dev *gc_dev = nullptr, *eb_dev = nullptr;  // the two CDF sets in HBM for the GPU coder
   PccWorkers workers;                  // the Q coder threads of the encoder
   DevPool pool;
@@ -514,11 +522,15 @@ int view_of(pcc_codec* cd, CS* s, View* v) {
 
 // rows given in canonical order -> rows of the (Morton-ordered) tensor (utils.sparse_from_rows)
 int rows_to_tensor(pcc_codec* cd, const View& v, const float* rows, int c, float** out) {
-  CODEC_ALLOC(inv, int32_t, std::max<int64_t>(v.n, 1));
   CODEC_ALLOC(o, float, std::max<int64_t>(v.n, 1) * c);
   if (v.n > 0) {
-    PCC_TRY(pcc_inverse_rows(cd->ctx, v.perm, v.n, v.n, inv));
-    PCC_TRY(pcc_gather_rows(cd->ctx, rows, (const uint32_t*)inv, v.n, 4 * c, o));
+    if ((4 * c) % 16 == 0 && (uintptr_t)rows % 16 == 0) {   // v.perm is a permutation: one scatter
+      PCC_TRY(pcc_scatter_rows(cd->ctx, rows, v.perm, v.n, 4 * c, o));
+    } else {
+      CODEC_ALLOC(inv, int32_t, v.n);
+      PCC_TRY(pcc_inverse_rows(cd->ctx, v.perm, v.n, v.n, inv));
+      PCC_TRY(pcc_gather_rows(cd->ctx, rows, (const uint32_t*)inv, v.n, 4 * c, o));
+    }
   }
   *out = o;
   return PCC_OK;
@@ -550,6 +562,33 @@ int scale_row(pcc_codec* cd, double qg, double qa, float* out /*[c_y]*/) {
     const float s = 0.5f + fabsf(o[j]);
     out[j] = s + e;
   }
+  return PCC_OK;
+}
+
+// the rows scale_nn(q) + eps of n_q quality settings in HBM (cached per codec: see pcc_codec::scale_slot)
+int scale_rows_dev(pcc_codec* cd, int slot, const double* h_q, int n_q, float** out) {
+  const int cy = cd->c_y;
+  pcc_codec::ScaleSlot& sl = cd->scale_slot[slot];
+  const std::vector<double> key(h_q, h_q + 2 * n_q);
+  if (sl.dev && sl.key == key) {
+    *out = sl.dev;
+    return PCC_OK;
+  }
+  std::vector<float> h((size_t)n_q * cy);
+  for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &h[(size_t)q * cy]));
+  if (sl.cap < h.size() * 4) {
+    PCC_HIP(hipStreamSynchronize(cd->ctx->stream));
+    if (sl.dev) PCC_HIP(hipFree(sl.dev));
+    sl.dev = nullptr;
+    sl.cap = 0;
+    PCC_HIP(hipMalloc((void**)&sl.dev, h.size() * 4));
+    sl.cap = h.size() * 4;
+  }
+  sl.key.clear();   // valid again only once the copy below has been queued
+  PCC_HIP(hipMemcpyAsync(sl.dev, h.data(), h.size() * 4, hipMemcpyHostToDevice, cd->ctx->stream));
+  PCC_HIP(hipStreamSynchronize(cd->ctx->stream));   // h leaves scope; once per change of settings
+  sl.key = key;
+  *out = sl.dev;
   return PCC_OK;
 }
 
@@ -891,6 +930,8 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
   if (!cd) return;
   if (cd->ctx) (void)pcc_sync(cd->ctx);
   for (auto& kv : cd->dev) (void)hipFree(kv.second);
+  for (auto& sl : cd->scale_slot)
+    if (sl.dev) (void)hipFree(sl.dev);
   pcc_rans_tables_free(cd->gc_tables);
   pcc_rans_dev_destroy(cd->gc_dev);
   pcc_rans_dev_destroy(cd->eb_dev);
@@ -1397,10 +1438,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     PCC_REQUIRE(cd->gc_dev && cd->eb_dev, PCC_E_ARG, "pcc_encode_gop: container version 1 without device CDF tables");
     float* params;
     PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
-    std::vector<float> scale_h((size_t)n_q * cy);
-    for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &scale_h[(size_t)q * cy]));
-    CODEC_ALLOC(scale_d, float, n_q * cy);
-    PCC_HIP(hipMemcpyAsync(scale_d, scale_h.data(), scale_h.size() * 4, hipMemcpyHostToDevice, st));
+    float* scale_d;
+    PCC_TRY(scale_rows_dev(cd, 0, h_q, n_q, &scale_d));
     const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
     PCC_REQUIRE(tab, PCC_E_ARG, "pcc_encode_gop: gaussian_conditional tables missing");
     const int64_t per = (int64_t)cy * ny, tot = per * n_q, nzs = (int64_t)cz * nz;
@@ -1450,10 +1489,8 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   } else {
     float* params;
     PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
-    std::vector<float> scale_h((size_t)n_q * cy);
-    for (int q = 0; q < n_q; ++q) PCC_TRY(scale_row(cd, h_q[2 * q], h_q[2 * q + 1], &scale_h[(size_t)q * cy]));
-    CODEC_ALLOC(scale_d, float, n_q * cy);
-    PCC_HIP(hipMemcpyAsync(scale_d, scale_h.data(), scale_h.size() * 4, hipMemcpyHostToDevice, st));
+    float* scale_d;
+    PCC_TRY(scale_rows_dev(cd, 0, h_q, n_q, &scale_d));
     const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
     const Tensor *gc_cdf = find(cd, "gaussian_conditional.quantized_cdf"), *gc_len = find(cd, "gaussian_conditional.cdf_length"),
                  *gc_off = find(cd, "gaussian_conditional.offset");
@@ -1943,10 +1980,9 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     PCC_TRY(view_of(cd, ycs, &yv));
     float* params;
     PCC_TRY(h_s_out_at(cd, gp, ycs, yv, &params));
-    std::vector<float> scale_h((size_t)cy);
-    PCC_TRY(scale_row(cd, qg, qa, scale_h.data()));
-    CODEC_ALLOC(scale_d, float, cy);
-    PCC_HIP(hipMemcpyAsync(scale_d, scale_h.data(), (size_t)cy * 4, hipMemcpyHostToDevice, st));
+    float* scale_d;
+    const double q_dec[2] = {qg, qa};
+    PCC_TRY(scale_rows_dev(cd, 1, q_dec, 1, &scale_d));
     const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
     const Tensor *gc_cdf = find(cd, "gaussian_conditional.quantized_cdf"), *gc_len = find(cd, "gaussian_conditional.cdf_length"),
                  *gc_off = find(cd, "gaussian_conditional.offset");

@@ -91,6 +91,8 @@ int pcc_sort_pairs_bytes(pcc_ctx* ctx, uint64_t* d_keys, uint32_t* d_perm, int64
 // sort.hip: canonical order + rows in that order of a small coordinate set given by its Morton keys
 int64_t pcc_sort_small_max();
 int pcc_sort_keys_canonical(pcc_ctx* ctx, const uint64_t* d_mkeys, int64_t n, uint32_t* d_perm, int32_t* d_sorted_coords);
+// sort.hip: dst[perm[i]] = src[i] for a permutation perm (pcc_inverse_rows + pcc_gather_rows in one launch)
+int pcc_scatter_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* d_perm, int64_t n, int row_bytes, void* d_dst);
 // octree.hip: the single-workgroup octree kernel without any read-back (codec.hip's geometry slot)
 int pcc_octree_small_max();
 int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,

@@ -1014,6 +1014,29 @@ extern "C" int pcc_gather_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* 
   return PCC_OK;
 }
 
+// internal (codec.hip): dst[perm[i]] = src[i] for a PERMUTATION perm of 0 .. n-1 — what pcc_inverse_rows followed by
+// pcc_gather_rows computes, in one launch (rows given in canonical order back into the tensor's row order)
+__global__ void k_scatter_rows16(const uint4* __restrict__ src, const uint32_t* __restrict__ perm, int64_t n, int vec,
+                                 uint4* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t / vec;
+  const int j = (int)(t - row * vec);
+  if (row >= n) return;
+  dst[(int64_t)perm[row] * vec + j] = src[row * vec + j];
+}
+int pcc_scatter_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* d_perm, int64_t n, int row_bytes, void* d_dst) {
+  PCC_REQUIRE(ctx && (n == 0 || (d_src && d_perm && d_dst)), PCC_E_ARG, "pcc_scatter_rows: null arg");
+  PCC_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0 && (uintptr_t)d_src % 16 == 0 && (uintptr_t)d_dst % 16 == 0, PCC_E_ARG,
+              "pcc_scatter_rows: rows of %d bytes (16-byte pieces of aligned tensors)", row_bytes);
+  if (n <= 0) return PCC_OK;
+  PccProfScope prof(ctx, "scatter_rows", n, row_bytes, 0, 0);
+  const int vec = row_bytes / 16;
+  hipLaunchKernelGGL(k_scatter_rows16, dim3(nblk(n * vec, 256)), dim3(256), 0, ctx->stream, (const uint4*)d_src, d_perm, n, vec,
+                     (uint4*)d_dst);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 extern "C" int pcc_gather_rows_or_zero(pcc_ctx* ctx, const float* d_src, const int32_t* d_rows,
                                        int64_t m, int c, float* d_dst) {
   PCC_REQUIRE(ctx && (m == 0 || (d_src && d_rows && d_dst)), PCC_E_ARG, "pcc_gather_rows_or_zero: null arg");
