@@ -124,6 +124,10 @@ def test_hip_containers_with_seek_points(oracle, wl):
         bad = bytearray(out[3])
         bad[off] ^= 0x21
         assert same(dec.decompress(bytes(bad))[0]), off
+    # the op-by-op engine reads the container field by field like the reference's read_bitstream_batched and never looks
+    # behind the last frame record
+    dec_ops = pkg("codec_parallel").DecompressionPipeline(slots=1, engine="ops")
+    assert same(dec_ops.decompress(out[3])[0])
     assert same(dec.decompress(out[3][:-5])[0])                    # a cut trailer
     assert same(dec.decompress(out[3] + b"tail")[0])               # bytes behind it
     with pytest.raises(ValueError):
