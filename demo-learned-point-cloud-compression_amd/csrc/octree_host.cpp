@@ -16,6 +16,8 @@
 // implied when the first seven are zero.
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
+#include <memory>
 #include <vector>
 #include "../../include/pcc.h"
 #include "rans_gate.h"
@@ -31,15 +33,39 @@ constexpr int kCtxPerClass = 36;
 constexpr int kClasses = 3;
 constexpr int kHeader = 24;
 
-inline int ctx_index(int depth, int level, int j, int ones) {
-  int cls = depth - 1 - level;
-  if (cls > kClasses - 1) cls = kClasses - 1;
-  return cls * kCtxPerClass + j * (j + 1) / 2 + ones;
-}
 inline void adapt(uint16_t& p1, int bit) {
-  if (bit) p1 = (uint16_t)(p1 + ((kProbOne - p1) >> 4));
-  else p1 = (uint16_t)(p1 - (p1 >> 4));
+  const uint32_t p = p1, up = p + ((kProbOne - p) >> 4), dn = p - (p >> 4);
+  p1 = (uint16_t)(bit ? up : dn);   // both sides computed: a conditional move, not a branch on a data bit
 }
+// first context of bit position j inside a level class (j (j + 1) / 2 + ones so far)
+constexpr int kTri[8] = {0, 1, 3, 6, 10, 15, 21, 28};
+inline int class_of(int depth, int level) {
+  const int cls = depth - 1 - level;
+  return cls > kClasses - 1 ? kClasses - 1 : cls;
+}
+// x / f for x < 2^63 and the 12-bit frequencies of the model without a division: multiply by ceil(2^(shift + 63) / f),
+// shift = ceil(log2 f) (Alverson; the form rans_host.cpp uses for the y coder, checked there against x / f)
+struct Recip {
+  uint64_t rcp;
+  uint32_t rs;
+};
+struct RecipTable {
+  Recip r[kProbOne + 1];
+  RecipTable() {
+    for (uint32_t f = 1; f <= kProbOne; ++f) {
+      if (f < 2) {
+        r[f] = {~0ull, 0};   // q = (x * (2^64 - 1)) >> 64 = x - 1 for x >= 1: never used (a frequency is >= 15)
+        continue;
+      }
+      uint32_t shift = 0;
+      while (f > (1u << shift)) ++shift;
+      r[f].rcp = (uint64_t)((((unsigned __int128)1 << (shift + 63)) + f - 1) / f);
+      r[f].rs = shift - 1;
+    }
+    r[0] = {0, 0};
+  }
+};
+const RecipTable kRecip;
 inline void put_u32(uint8_t* p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
 inline uint32_t get_u32(const uint8_t* p) {
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -79,14 +105,14 @@ extern "C" int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, i
   // forward modelling pass
   int64_t total_nodes = 0;
   for (int L = 0; L < depth; ++L) total_nodes += h_level_n[L];
-  std::vector<uint16_t> probs;
-  std::vector<uint8_t> bits;
-  probs.reserve((size_t)total_nodes * 8);
-  bits.reserve((size_t)total_nodes * 8);
+  // one record per decision: probability of a one | bit << 15 (the probability stays below 4096)
+  std::unique_ptr<uint16_t[]> recs(new uint16_t[(size_t)total_nodes * 8 + 8]);
+  size_t n_rec = 0;
   uint16_t model[kClasses * kCtxPerClass];
   for (auto& m : model) m = kProbOne / 2;
   int64_t pos = 0;
   for (int L = 0; L < depth; ++L) {
+    uint16_t* mc = model + class_of(depth, L) * kCtxPerClass;
     for (int64_t i = 0; i < h_level_n[L]; ++i, ++pos) {
       const uint32_t byte = h_occ[pos];
       if (byte == 0) {
@@ -94,33 +120,34 @@ extern "C" int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, i
         return PCC_E_ARG;
       }
       int ones = 0;
-      for (int j = 0; j < 8; ++j) {
+      const int last = (byte & 0x7Fu) ? 8 : 7;   // the eighth bit is implied behind seven zeros
+      for (int j = 0; j < last; ++j) {
         const int bit = (byte >> j) & 1;
-        if (j == 7 && ones == 0) break;  // implied 1
-        uint16_t& m = model[ctx_index(depth, L, j, ones)];
-        probs.push_back(m);
-        bits.push_back((uint8_t)bit);
+        uint16_t& m = mc[kTri[j] + ones];
+        recs[n_rec++] = (uint16_t)(m | (bit << 15));
         adapt(m, bit);
         ones += bit;
       }
     }
   }
   // reverse rANS pass
-  std::vector<uint32_t> words(bits.size() / 2 + 8);
+  std::vector<uint32_t> words(n_rec / 2 + 8);
   uint32_t* end = words.data() + words.size();
   uint32_t* ptr = end;
   uint64_t x = kRansL;
-  for (int64_t k = (int64_t)bits.size() - 1; k >= 0; --k) {
-    const uint32_t p1 = probs[(size_t)k];
-    const uint32_t start = bits[(size_t)k] ? (kProbOne - p1) : 0u;
-    const uint32_t freq = bits[(size_t)k] ? p1 : (kProbOne - p1);
+  for (int64_t k = (int64_t)n_rec - 1; k >= 0; --k) {
+    const uint32_t r = recs[(size_t)k], p1 = r & 0x7FFFu, bit = r >> 15;
+    const uint32_t start = bit ? (kProbOne - p1) : 0u;
+    const uint32_t freq = bit ? p1 : (kProbOne - p1);
     const uint64_t x_max = ((kRansL >> kProbBits) << 32) * freq;
     if (x >= x_max) {
       if (ptr == words.data()) { pcc_set_error("pcc_octree_pack: internal overflow"); return PCC_E_NOMEM; }
       *--ptr = (uint32_t)x;
       x >>= 32;
     }
-    x = ((x / freq) << kProbBits) + (x % freq) + start;
+    const Recip& rc = kRecip.r[freq];
+    const uint64_t q = (uint64_t)(((unsigned __int128)rc.rcp * x) >> 64) >> rc.rs;   // == x / freq (x < 2^63)
+    x = (q << kProbBits) + (x - q * freq) + start;
   }
   if (ptr - words.data() < 2) { pcc_set_error("pcc_octree_pack: internal overflow"); return PCC_E_NOMEM; }
   *--ptr = (uint32_t)(x >> 32);
@@ -205,34 +232,50 @@ static int octree_decode_cells(const uint8_t* h_in, int64_t len, std::vector<uin
   std::vector<uint64_t> cur(1, 0ull), nxt;
   for (int L = 0; L < depth; ++L) {
     if (h_level_n) h_level_n[L] = (int64_t)cur.size();
-    nxt.clear();
+    // the next level has at most 8 nodes per node of this one (decoded, so real) and at most n + 7 before the count
+    // check below fires: sized by what the stream has shown so far, written through a pointer
+    const size_t room = (size_t)std::min<int64_t>(8 * (int64_t)cur.size(), n + 8);
+    nxt.resize(room);
+    uint64_t* out = nxt.data();
+    size_t cnt = 0;
+    uint16_t* mc = model + class_of(depth, L) * kCtxPerClass;
     for (size_t i = 0; i < cur.size(); ++i) {
+      const uint64_t base = cur[i] << 3;
       int ones = 0;
-      for (int j = 0; j < 8; ++j) {
-        int bit;
-        if (j == 7 && ones == 0) {
-          bit = 1;
-        } else {
-          uint16_t& m = model[ctx_index(depth, L, j, ones)];
-          const uint32_t p1 = m;
-          const uint32_t cum = (uint32_t)(x & (kProbOne - 1));
-          bit = cum >= (kProbOne - p1) ? 1 : 0;
-          const uint32_t start = bit ? (kProbOne - p1) : 0u;
-          const uint32_t freq = bit ? p1 : (kProbOne - p1);
-          x = (uint64_t)freq * (x >> kProbBits) + cum - start;
-          if (x < kRansL) x = (x << 32) | word(bad);
-          adapt(m, bit);
-        }
-        if (bit) {
-          nxt.push_back((cur[i] << 3) | (uint64_t)j);
-          ones++;
-        }
+      for (int j = 0; j < 7; ++j) {
+        uint16_t& m = mc[kTri[j] + ones];
+        const uint32_t p1 = m;
+        const uint32_t cum = (uint32_t)(x & (kProbOne - 1));
+        const int bit = cum >= (kProbOne - p1) ? 1 : 0;
+        const uint32_t start = bit ? (kProbOne - p1) : 0u;
+        const uint32_t freq = bit ? p1 : (kProbOne - p1);
+        x = (uint64_t)freq * (x >> kProbBits) + cum - start;
+        if (x < kRansL) x = (x << 32) | word(bad);
+        adapt(m, bit);
+        out[cnt] = base | (uint64_t)j;   // written always, kept when the bit is set
+        cnt += (size_t)bit;
+        ones += bit;
       }
-      if (bad || (int64_t)nxt.size() > n) {
+      int bit7 = 1;   // implied behind seven zeros
+      if (ones != 0) {
+        uint16_t& m = mc[kTri[7] + ones];
+        const uint32_t p1 = m;
+        const uint32_t cum = (uint32_t)(x & (kProbOne - 1));
+        bit7 = cum >= (kProbOne - p1) ? 1 : 0;
+        const uint32_t start = bit7 ? (kProbOne - p1) : 0u;
+        const uint32_t freq = bit7 ? p1 : (kProbOne - p1);
+        x = (uint64_t)freq * (x >> kProbBits) + cum - start;
+        if (x < kRansL) x = (x << 32) | word(bad);
+        adapt(m, bit7);
+      }
+      out[cnt] = base | 7ull;
+      cnt += (size_t)bit7;
+      if (bad || (int64_t)cnt > n) {
         pcc_set_error("pcc_octree_unpack: corrupt stream at level %d", L);
         return PCC_E_STREAM;
       }
     }
+    nxt.resize(cnt);
     cur.swap(nxt);
   }
   if ((int64_t)cur.size() != n) {
