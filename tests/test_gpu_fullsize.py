@@ -70,6 +70,7 @@ def check_oracle_parity(codec, oracle, wl, frames):
         for a, b in zip(rec, oref):
             assert np.array_equal(a["points"], b["points"]), f"quality {q}: decoded occupancy differs"
             assert np.array_equal(a["colors"], b["colors"]), f"quality {q}: decoded colours differ"
+    return out
 
 
 def check_roundtrip(codec, wl, frames):
@@ -147,10 +148,19 @@ def test_gop_of_two_large_frames_equals_oracle(codec, oracle, wl):
 
 def test_single_frame_with_a_latent_beyond_the_small_kernels_equals_oracle(codec, oracle, wl):
     """one 3M-voxel frame (the fused scan uncut): ~80k latent rows, past the single-workgroup octree / sort / order
-    kernels (65536 rows) — the geometry slot takes its level-by-level form, the y order its multi-kernel sort"""
+    kernels (65536 rows) — the geometry slot is blob version 2 (levels, entropy coder and decoder on the GPU,
+    csrc/octree2.hip), the y order the multi-kernel sort; the op-by-op engine writes and reads the same container"""
     frame = wl.fused_scan(3_000_000, seed=2)
     assert frame["points"].shape[0] > 2_900_000
-    check_oracle_parity(codec, oracle, wl, [frame])
+    out = check_oracle_parity(codec, oracle, wl, [frame])
+    assert parse(out[3])[7][0][1] == 2                           # the slot's blob version
+    enc_o = pkg("codec_pipeline").CompressionPipeline(SETTINGS, slots=1, engine="ops")
+    dec_o = pkg("codec_parallel").DecompressionPipeline(slots=1, engine="ops")
+    out_o, _ = enc_o.compress(wl.gop([dict(frame)]))
+    assert all(out_o[q] == out[q] for q in (1, 2, 3))
+    rec_o, _ = dec_o.decompress(out[3])
+    rec, _ = codec[1].decompress(out[3])
+    assert np.array_equal(rec_o[0]["points"], rec[0]["points"]) and np.array_equal(rec_o[0]["colors"], rec[0]["colors"])
 
 
 def test_gop_with_ragged_frames(codec, wl):
