@@ -28,4 +28,7 @@ def __getattr__(name):
     if name == "ColorModel":
         from .model import ColorModel
         return ColorModel
+    if name in ("utils", "runtime", "workloads", "tiled", "metrics", "service", "capture"):   # submodules by attribute
+        import importlib
+        return importlib.import_module("." + name, __name__)
     raise AttributeError(name)
