@@ -215,7 +215,13 @@ def launch_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst, failed_at = 0, None
     live = dict(enumerate(procs))
+    t_start, limit = time.time(), float(os.environ.get("PCC_BENCH_RANK_TIMEOUT", "1500"))
     while live:
+        if failed_at is None and time.time() - t_start > limit:   # a rank that never returns (a collective that hangs)
+            log(f"bench.py: ranks still running after {limit:.0f} s: ending them, no line printed")
+            worst, failed_at = 3, time.time()
+            for q in live.values():
+                q.terminate()
         for r, p in list(live.items()):
             rc = p.poll()
             if rc is None:
