@@ -82,6 +82,44 @@ def test_seek_points_of_the_host_coder(oracle, n, points):
         assert (xo.value, wo.value) != (pos[2] if len(pos) > 2 else (0, len(stream) // 4))
 
 
+def test_seek_point_known_answer(oracle):
+    """Worked by hand.  One table, cdf = [0, 16384, 32768, 65536]: symbols 0 and 1 with frequency 2^14 each, the last
+    bin (2^15) the escape bin.  Symbols [0, 1, 0, 1], one seek point at index 2.  rANS64 (L = 2^31, 16-bit precision),
+    coded last symbol first; a step is x -> ((x / f) << 16) + x % f + start, and no state here reaches the
+    renormalisation threshold ((L >> 16) << 32) f = 2^61:
+      i = 3, s = 1 (start 2^14): x = (2^31 >> 14 << 16) + 0 + 2^14            = 2^33 + 2^14
+      i = 2, s = 0 (start 0)   : x = ((2^33 + 2^14) >> 14 << 16) + 0          = 2^35 + 2^16     <- symbols >= 2 are coded
+      i = 1, s = 1             : x = ((2^35 + 2^16) >> 14 << 16) + 0 + 2^14   = 2^37 + 2^18 + 2^14
+      i = 0, s = 0             : x = ((2^37 + 2^18 + 2^14) >> 14 << 16) + 0   = 2^39 + 2^20 + 2^16
+    stream = the final state, low word first (8 bytes, no renormalisation word).  A decoder has consumed those 2 words
+    when symbol 2 is next, and its state there is 2^35 + 2^16; decoding [2, 4) from the point gives [0, 1] and ends on
+    the coder's initial state 2^31 with still 2 words consumed."""
+    lib = pkg("_abi").lib()
+    cdf = np.array([[0, 16384, 32768, 65536]], np.int32)
+    sizes, offs = np.array([4], np.int32), np.array([0], np.int32)
+    sym, idx = np.array([0, 1, 0, 1], np.int32), np.zeros(4, np.int32)
+    stream, st, wd = _encode_seek(lib, sym, idx, cdf, sizes, offs, [2])
+    x_final = (1 << 39) + (1 << 20) + (1 << 16)
+    assert stream == struct.pack("<II", x_final & 0xFFFFFFFF, x_final >> 32)
+    assert int(st[0]) == (1 << 35) + (1 << 16) and int(wd[0]) == 2
+    o_st, o_wd = np.zeros(1, np.uint64), np.zeros(1, np.int64)
+    out = np.empty(64, np.uint8)
+    si = np.array([2], np.int64)
+    oracle.lib.orc_rans_encode_seek.restype = C.c_int64
+    got = oracle.lib.orc_rans_encode_seek(_p(sym), _p(idx), C.c_int64(4), _p(cdf), C.c_int(4), _p(sizes), _p(offs), _p(out), C.c_int64(64),
+                                          _p(si), C.c_int(1), _p(o_st), _p(o_wd))
+    assert out[:got].tobytes() == stream and int(o_st[0]) == int(st[0]) and int(o_wd[0]) == 2
+    dec = np.full(4, -9, np.int32)
+    xo, wo = C.c_uint64(0), C.c_int64(0)
+    buf = np.frombuffer(stream, np.uint8)
+    rc = lib.pcc_rans_decode_range(_p(buf), len(stream), _p(idx), 4, _p(cdf), 4, _p(sizes), _p(offs), 1, _p(dec), 2, 4,
+                                   C.c_uint64(int(st[0])), 2, C.byref(xo), C.byref(wo))
+    assert rc == 0 and dec.tolist() == [-9, -9, 0, 1] and xo.value == 1 << 31 and wo.value == 2
+    rc = lib.pcc_rans_decode_range(_p(buf), len(stream), _p(idx), 4, _p(cdf), 4, _p(sizes), _p(offs), 1, _p(dec), 0, 2,
+                                   C.c_uint64(0), 0, C.byref(xo), C.byref(wo))
+    assert rc == 0 and dec.tolist() == [0, 1, 0, 1] and xo.value == int(st[0]) and wo.value == 2
+
+
 def test_trailer_is_behind_the_reference_container(oracle, wl):
     """the oracle: with seek points the container is the plain container + trailer, and its reader — the reference's
     reader, codec_parallel.py:173-216 — stops in front of the trailer: same reconstruction"""
