@@ -163,6 +163,22 @@ def test_single_frame_with_a_latent_beyond_the_small_kernels_equals_oracle(codec
     assert np.array_equal(rec_o[0]["points"], rec[0]["points"]) and np.array_equal(rec_o[0]["colors"], rec[0]["colors"])
 
 
+def test_gop_mixing_both_blob_versions(codec, wl):
+    """a GOP whose first frame has a latent above 65536 rows (geometry blob version 2, coded and decoded by the GPU) and
+    whose second frame has a small one (version 1, host coder): the slots carry the two versions side by side, and
+    every frame decodes to what it decodes to when coded alone (frames of a GOP do not interact)"""
+    enc, dec = codec
+    big, small = wl.fused_scan(3_000_000, seed=2), wl.sphere_shell(64, 25.2, seed=1, offset=(40, -90, 300))
+    out, _ = enc.compress(wl.gop([dict(big), dict(small)]))
+    blobs = parse(out[3])[7]
+    assert [b[1] for b in blobs] == [2, 1]
+    rec, _ = dec.decompress(out[3])
+    for frame, got in zip((big, small), rec):
+        alone, _ = enc.compress(wl.gop([dict(frame)]))
+        want, _ = dec.decompress(alone[3])
+        assert np.array_equal(got["points"], want[0]["points"]) and np.array_equal(got["colors"], want[0]["colors"])
+
+
 def test_gop_with_ragged_frames(codec, wl):
     tiny = {"points": np.array([[5, -3, 9]], dtype=np.int16), "colors": np.array([[0.2, 0.4, 0.6]])}
     frames = [wl.sphere_shell(64, 25.2, seed=1), tiny, wl.room(120_000, seed=3), wl.sphere_shell(24, 9.1, seed=2,
