@@ -103,6 +103,7 @@ PROTOTYPES = {
     "pcc_derive_map_down": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, vp]),
     "pcc_inverse_rows": (i32, [vp, vp, i64, i64, vp]),
     "pcc_up_coords": (i32, [vp, vp, i64, i32, vp]),
+    "pcc_up_coords_rows": (i32, [vp, vp, i64, i32, vp, i64, vp]),
     "pcc_build_map": (i32, [vp, vp, i64, i32, vp]),
     "pcc_lookup": (i32, [vp, vp, i64, vp, i64, vp]),
     "pcc_gather_rows_or_zero": (i32, [vp, vp, vp, i64, i32, vp]),
@@ -111,6 +112,7 @@ PROTOTYPES = {
     "pcc_convT_gen": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "pcc_linear": (i32, [vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "pcc_topk_prune": (i32, [vp, vp, i64, i32, pi64, pi64, vp, pi64]),
+    "pcc_topk_prune_map": (i32, [vp, vp, i64, i32, pi64, pi64, vp, pi64, vp]),
     "pcc_factorized_quant": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "pcc_factorized_dequant": (i32, [vp, vp, i64, i32, vp, vp]),
     "pcc_gaussian_quant": (i32, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp]),

@@ -164,6 +164,7 @@ struct CS {
   std::vector<int64_t> down_counts;  // row counts of the successive parent levels, when known (pcc_level_counts)
   CS* subset_of = nullptr;   // candidate set this set was pruned from, with the kept rows
   uint32_t* keep = nullptr;
+  int32_t* keep_remap = nullptr;   // [subset_of->n] position of a candidate among the kept rows or -1, when the pruning wrote it
 };
 
 struct Feat {  // sparse tensor = coordinate set + feature rows
@@ -328,6 +329,8 @@ CS* new_set(pcc_codec* cd, uint64_t* keys, int64_t n, int stride, int n_batch) {
   return s;
 }
 
+int keys_of(pcc_codec* cd, CS* s, uint64_t** out);
+
 int offsets_of(pcc_codec* cd, CS* s, const std::vector<int64_t>** out) {
   if (s->offsets.empty()) {
     if (s->n_batch == 1) {
@@ -348,6 +351,8 @@ int offsets_of(pcc_codec* cd, CS* s, const std::vector<int64_t>** out) {
 
 int down_of(pcc_codec* cd, CS* s) {
   if (s->down) return PCC_OK;
+  uint64_t* skeys;
+  PCC_TRY(keys_of(cd, s, &skeys));
   const int64_t cap = std::max<int64_t>(s->n, 1);
   CODEC_ALLOC(pkeys, uint64_t, cap);
   CODEC_ALLOC(nbr8, int32_t, 8 * cap);
@@ -355,9 +360,9 @@ int down_of(pcc_codec* cd, CS* s) {
   int64_t m = 0;
   if (s->n > 0 && !s->down_counts.empty()) {  // size known: no read-back, the stream keeps running
     m = s->down_counts[0];
-    PCC_TRY(pcc_down_coords_known(cd->ctx, s->keys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, m));
+    PCC_TRY(pcc_down_coords_known(cd->ctx, skeys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, m));
   } else if (s->n > 0) {
-    PCC_TRY(pcc_down_coords(cd->ctx, s->keys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, &m));
+    PCC_TRY(pcc_down_coords(cd->ctx, skeys, s->n, 3 * log2i(s->stride), pkeys, nbr8, s->n, parent_of, &m));
   }
   s->down = new_set(cd, pkeys, m, s->stride * 2, s->n_batch);
   if (s->down_counts.size() > 1) s->down->down_counts.assign(s->down_counts.begin() + 1, s->down_counts.end());
@@ -375,12 +380,25 @@ int up_of(pcc_codec* cd, CS* s, CS** out) {
     pcc_set_error("codec: cannot up-sample a stride-1 coordinate set");
     return PCC_E_ARG;
   }
-  CODEC_ALLOC(ckeys, uint64_t, std::max<int64_t>(8 * s->n, 1));
-  if (s->n > 0) PCC_TRY(pcc_up_coords(cd->ctx, s->keys, s->n, 3 * (log2i(s->stride) - 1), ckeys));
-  CS* c = new_set(cd, ckeys, 8 * s->n, s->stride / 2, s->n_batch);
+  // no keys yet: row 8p + o is octant o of parent p, and what follows an up stage (the rule book derived from the
+  // parents', the top-k's kept keys) works from the parents' keys — keys_of() writes the 8N keys for whoever asks
+  CS* c = new_set(cd, nullptr, 8 * s->n, s->stride / 2, s->n_batch);
   c->gen_parent = s;
   s->up = c;
   *out = c;
+  return PCC_OK;
+}
+
+int keys_of(pcc_codec* cd, CS* s, uint64_t** out) {
+  if (!s->keys) {
+    PCC_REQUIRE(s->gen_parent, PCC_E_ARG, "codec: coordinate set without keys");
+    uint64_t* pk;
+    PCC_TRY(keys_of(cd, s->gen_parent, &pk));
+    CODEC_ALLOC(ckeys, uint64_t, std::max<int64_t>(s->n, 1));
+    if (s->n > 0) PCC_TRY(pcc_up_coords(cd->ctx, pk, s->gen_parent->n, 3 * log2i(s->stride), ckeys));
+    s->keys = ckeys;
+  }
+  *out = s->keys;
   return PCC_OK;
 }
 
@@ -401,17 +419,25 @@ int nbr27_of(pcc_codec* cd, CS* s, int32_t** out) {
       CS* cand = s->subset_of;
       int32_t* pn;
       PCC_TRY(nbr27_of(cd, cand->gen_parent, &pn));
-      CODEC_ALLOC(remap, int32_t, cand->n);
-      PCC_TRY(pcc_inverse_rows(cd->ctx, s->keep, s->n, cand->n, remap));
+      int32_t* remap = s->keep_remap;
+      if (!remap) {
+        remap = (int32_t*)cd->pool.alloc(sizeof(int32_t) * (size_t)cand->n);
+        if (!remap) return PCC_E_NOMEM;
+        PCC_TRY(pcc_inverse_rows(cd->ctx, s->keep, s->n, cand->n, remap));
+      }
       PCC_TRY(pcc_subset_map_up(cd->ctx, pn, cand->gen_parent->n, s->keep, remap, s->n, nbr));
     } else if (s->n > kHashBuildMax && s->stride <= 4096) {
       PCC_TRY(down_of(cd, s));
       int32_t* pn;
       PCC_TRY(nbr27_of(cd, s->down, &pn));
-      PCC_TRY(pcc_derive_map_down(cd->ctx, pn, s->down->n, s->nbr8, s->parent_of, s->keys, s->n,
+      uint64_t* skeys;
+      PCC_TRY(keys_of(cd, s, &skeys));
+      PCC_TRY(pcc_derive_map_down(cd->ctx, pn, s->down->n, s->nbr8, s->parent_of, skeys, s->n,
                                   3 * log2i(s->stride), nbr));
     } else {
-      PCC_TRY(pcc_build_map(cd->ctx, s->keys, s->n, s->stride, nbr));
+      uint64_t* skeys;
+      PCC_TRY(keys_of(cd, s, &skeys));
+      PCC_TRY(pcc_build_map(cd->ctx, skeys, s->n, s->stride, nbr));
     }
     s->nbr27 = nbr;
   }
@@ -504,15 +530,17 @@ int view_of(pcc_codec* cd, CS* s, View* v) {
   const int64_t cap = std::max<int64_t>(s->n, 1);
   CODEC_ALLOC(perm, uint32_t, cap);
   CODEC_ALLOC(cs, int32_t, 4 * cap);
+  uint64_t* skeys;
+  PCC_TRY(keys_of(cd, s, &skeys));
   if (s->n > 0 && s->n <= pcc_sort_small_max()) {
     // latent-sized set: order and ordered rows straight from the keys
-    PCC_TRY(pcc_sort_keys_canonical(cd->ctx, s->keys, s->n, perm, cs));
+    PCC_TRY(pcc_sort_keys_canonical(cd->ctx, skeys, s->n, perm, cs));
     *v = {cs, perm, s->n};
     return PCC_OK;
   }
   CODEC_ALLOC(c, int32_t, 4 * cap);
   if (s->n > 0) {
-    PCC_TRY(pcc_keys_to_coords(cd->ctx, s->keys, s->n, c));
+    PCC_TRY(pcc_keys_to_coords(cd->ctx, skeys, s->n, c));
     PCC_TRY(pcc_sort_coords(cd->ctx, c, s->n, perm));
     PCC_TRY(pcc_gather_rows(cd->ctx, c, perm, s->n, 16, cs));
   }
@@ -592,22 +620,6 @@ int scale_rows_dev(pcc_codec* cd, int slot, const double* h_q, int n_q, float** 
   return PCC_OK;
 }
 
-// Row of every latent voxel among the 64 generated descendants of its stride-32 ancestor: the descendants are laid
-// out as row = (8 z_row + octant at stride 16) * 8 + octant at stride 8, and the two stride-2 coordinate maps that
-// produced z from y hold the ancestors — no hash table, no lookup.  j runs over the latent's canonical order.
-__global__ __launch_bounds__(256) void k_descendant_rows(const uint32_t* __restrict__ perm,
-                                                         const uint64_t* __restrict__ ykeys,
-                                                         const int32_t* __restrict__ parent_of8,
-                                                         const int32_t* __restrict__ parent_of16, int64_t m,
-                                                         int32_t* __restrict__ rows) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  const uint32_t r = perm[j];
-  const uint64_t k = ykeys[r];
-  const int32_t p32 = parent_of16[parent_of8[r]];
-  rows[j] = (int32_t)((((int64_t)p32 * 8 + (int64_t)((k >> 12) & 7ull)) * 8) + (int64_t)((k >> 9) & 7ull));
-}
-
 // h_s up to its output layer: the 64 generated descendants of every z voxel at stride 8 with their features
 int h_s_up(pcc_codec* cd, const Feat& z_hat, Feat* pre) {
   Feat a;
@@ -626,33 +638,39 @@ int h_s_out_at(pcc_codec* cd, const Feat& pre, const CS* ycs, const View& yv, fl
   PCC_TRY(wb(cd, "h_s.conv0", &w, &b, &tw));
   const int cin = (int)tw->dims[1], cout = (int)tw->dims[2];
   const int64_t cap = std::max<int64_t>(m, 1);
-  CODEC_ALLOC(qkeys, uint64_t, cap);
-  CODEC_ALLOC(flag, int32_t, 1);
-  CODEC_ALLOC(rows, int32_t, cap);
-  CODEC_ALLOC(self, int32_t, cap);
   CODEC_ALLOC(nbr_sub, int32_t, 27 * cap);
-  CODEC_ALLOC(conv_o, float, cap * cout);
   CODEC_ALLOC(o, float, cap * cout);
   if (m > 0) {
-    int32_t* nbr;
-    PCC_TRY(nbr27_of(cd, pre.cs, &nbr));
     const CS* z16 = ycs->down;
     const CS* z32 = z16 ? z16->down : nullptr;
     const bool by_structure = ycs->stride == 8 && ycs->n == m && z32 && ycs->parent_of && z16->parent_of &&
                               pre.cs->gen_parent && pre.cs->gen_parent->gen_parent == z32;
-    if (by_structure) {  // pre = up(up(z)) and z = down(down(y)): the rows follow from the two parent maps
-      hipLaunchKernelGGL(k_descendant_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, cd->ctx->stream,
-                         (const uint32_t*)yv.perm, (const uint64_t*)ycs->keys, (const int32_t*)ycs->parent_of,
-                         (const int32_t*)z16->parent_of, m, rows);
-      PCC_CHECK_LAUNCH();
+    if (by_structure) {
+      // pre = up(up(z)) and z = down(down(y)): every latent voxel IS one of the 64 descendants of its stride-32
+      // ancestor, its row and its rule-book column follow from the two parent maps and the book one level up — no
+      // hash table, no lookup, no book of the descendants, and no row is absent (o = the conv's output as it is)
+      int32_t* pn;
+      PCC_TRY(nbr27_of(cd, pre.cs->gen_parent, &pn));
+      PCC_TRY(pcc_descendant_map(cd->ctx, pn, pre.cs->gen_parent->n, (const uint32_t*)yv.perm, (const uint64_t*)ycs->keys,
+                                 (const int32_t*)ycs->parent_of, (const int32_t*)z16->parent_of, m, nbr_sub));
+      PCC_TRY(pcc_sparse_conv(cd->ctx, pre.f, pre.cs->n, nbr_sub, 27, m, m, w, b, cin, cout, 0, o));
     } else {  // general form: hash the descendants' keys and look the coordinates up
+      int32_t* nbr;
+      PCC_TRY(nbr27_of(cd, pre.cs, &nbr));
+      CODEC_ALLOC(qkeys, uint64_t, cap);
+      CODEC_ALLOC(flag, int32_t, 1);
+      CODEC_ALLOC(rows, int32_t, cap);
+      CODEC_ALLOC(self, int32_t, cap);
+      CODEC_ALLOC(conv_o, float, cap * cout);
       PCC_HIP(hipMemsetAsync(flag, 0, 4, cd->ctx->stream));
       PCC_TRY(pcc_morton_keys(cd->ctx, qcoords, m, qkeys, flag));
-      PCC_TRY(pcc_lookup(cd->ctx, pre.cs->keys, pre.cs->n, qkeys, m, rows));
+      uint64_t* pre_keys;
+      PCC_TRY(keys_of(cd, pre.cs, &pre_keys));
+      PCC_TRY(pcc_lookup(cd->ctx, pre_keys, pre.cs->n, qkeys, m, rows));
+      PCC_TRY(pcc_gather_map_columns(cd->ctx, nbr, 27, pre.cs->n, rows, m, nbr_sub, self));
+      PCC_TRY(pcc_sparse_conv(cd->ctx, pre.f, pre.cs->n, nbr_sub, 27, m, m, w, b, cin, cout, 0, conv_o));
+      PCC_TRY(pcc_gather_rows_or_zero(cd->ctx, conv_o, self, m, cout, o));
     }
-    PCC_TRY(pcc_gather_map_columns(cd->ctx, nbr, 27, pre.cs->n, rows, m, nbr_sub, self));
-    PCC_TRY(pcc_sparse_conv(cd->ctx, pre.f, pre.cs->n, nbr_sub, 27, m, m, w, b, cin, cout, 0, conv_o));
-    PCC_TRY(pcc_gather_rows_or_zero(cd->ctx, conv_o, self, m, cout, o));
   }
   *out = o;
   return PCC_OK;
@@ -2130,19 +2148,33 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
     CODEC_ALLOC(keep, uint32_t, std::max<int64_t>(nu, 1));
     // exact top-k keeps sum_f kj[f] rows: no count to read back, the stage stays asynchronous
     const int64_t n_keep = new_offs.back();
-    if (nu > 0) PCC_TRY(pcc_topk_prune(ctx, logits, nu, nb, offs->data(), kj.data(), keep, nullptr));
+    // the stages that are followed by another want the rule book of what they keep (nbr27_of): the placement writes the
+    // candidates' positions among the kept rows as it goes
+    int32_t* keep_remap = nullptr;
+    if (nu > 0 && j + 1 < 3) {
+      keep_remap = (int32_t*)cd->pool.alloc(sizeof(int32_t) * (size_t)nu);
+      if (!keep_remap) return PCC_E_NOMEM;
+    }
+    if (nu > 0) PCC_TRY(pcc_topk_prune_map(ctx, logits, nu, nb, offs->data(), kj.data(), keep, nullptr, keep_remap));
     CODEC_ALLOC(pkeys, uint64_t, std::max<int64_t>(n_keep, 1));
     CODEC_ALLOC(pf, float, std::max<int64_t>(n_keep, 1) * cout);
     // the kept rows stay where they are: the next up stage / the colour head read them through `keep`
     const bool in_place = cout == 32;
     if (n_keep > 0) {
-      PCC_TRY(pcc_gather_rows(ctx, u.cs->keys, keep, n_keep, 8, pkeys));
+      if (!u.cs->keys && u.cs->gen_parent) {   // the kept candidates' keys from their parents': the 8N are never written
+        uint64_t* pk;
+        PCC_TRY(keys_of(cd, u.cs->gen_parent, &pk));
+        PCC_TRY(pcc_up_coords_rows(ctx, pk, u.cs->gen_parent->n, 3 * log2i(u.cs->stride), keep, n_keep, pkeys));
+      } else {
+        PCC_TRY(pcc_gather_rows(ctx, u.cs->keys, keep, n_keep, 8, pkeys));
+      }
       if (!in_place) PCC_TRY(pcc_gather_rows(ctx, feats, keep, n_keep, 4 * cout, pf));
     }
     CS* ps = new_set(cd, pkeys, n_keep, u.cs->stride, nb);
     ps->offsets = new_offs;
     ps->subset_of = u.cs;
     ps->keep = keep;
+    ps->keep_remap = keep_remap;
     h = {ps, in_place ? feats : pf, cout, in_place ? keep : nullptr};
   }
   {
@@ -2163,7 +2195,9 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
         PCC_TRY(pcc_linear(ctx, pf, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
       } else
         PCC_TRY(pcc_linear(ctx, h.f, nr, w, b, (int)tw->dims[0], (int)tw->dims[1], 0, rgb));
-      PCC_TRY(pcc_keys_to_coords(ctx, h.cs->keys, nr, coords));
+      uint64_t* hkeys;
+      PCC_TRY(keys_of(cd, h.cs, &hkeys));
+      PCC_TRY(pcc_keys_to_coords(ctx, hkeys, nr, coords));
     }
     cd->rec_coords = coords;
     cd->rec_colors = rgb;

@@ -60,6 +60,11 @@ struct pcc_ctx {
   // pinned staging grown on demand (octree2.hip: blobs and decoded points on their way over PCIe)
   void* stage;
   size_t stage_cap;
+  // topk.hip: the histograms of GOPs of up to 8 frames, two buffers used in turn (one hipMalloc; each call's last
+  // launch clears the other buffer for the next call)
+  uint32_t* topk_hist[2];
+  bool topk_clean[2];
+  int topk_next;
 };
 
 struct pcc_prof_rec {
@@ -93,6 +98,10 @@ int64_t pcc_sort_small_max();
 int pcc_sort_keys_canonical(pcc_ctx* ctx, const uint64_t* d_mkeys, int64_t n, uint32_t* d_perm, int32_t* d_sorted_coords);
 // sort.hip: dst[perm[i]] = src[i] for a permutation perm (pcc_inverse_rows + pcc_gather_rows in one launch)
 int pcc_scatter_rows(pcc_ctx* ctx, const void* d_src, const uint32_t* d_perm, int64_t n, int row_bytes, void* d_dst);
+// map.hip: rule-book columns of a latent's voxels among the 64 generated descendants of their stride-32 ancestors
+int pcc_descendant_map(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t parent_pitch, const uint32_t* d_perm,
+                       const uint64_t* d_ykeys, const int32_t* d_parent_of8, const int32_t* d_parent_of16, int64_t m,
+                       int32_t* d_nbr);
 // octree.hip: the single-workgroup octree kernel without any read-back (codec.hip's geometry slot)
 int pcc_octree_small_max();
 int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,

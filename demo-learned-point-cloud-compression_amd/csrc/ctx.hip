@@ -53,6 +53,7 @@ extern "C" void pcc_destroy(pcc_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->stage) (void)hipHostFree(c->stage);
+  if (c->topk_hist[0]) (void)hipFree(c->topk_hist[0]);   // one allocation holds both
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   for (int i = 0; i < c->prof_cap; ++i)

@@ -241,6 +241,49 @@ __global__ __launch_bounds__(256) void k_subset_map_up(const int32_t* __restrict
   for (int k = 0; k < 27; ++k) nbr[(int64_t)k * n_keep + j] = pr[k];
 }
 
+// Rule-book columns of a latent's voxels among the 64 generated descendants of their stride-32 ancestors (h_s ends in a
+// conv that is sampled at the latent's coordinates only).  The descendants are row = (8 z_row + octant at stride 16)
+// * 8 + octant at stride 8, and the two stride-2 maps that produced z from y hold the ancestors: the row of voxel
+// perm[j], then its 27 neighbours from the book of the 8 z_rows rows at stride 16 — the book of the 64 z_rows
+// descendants never exists, nor the row list.
+__global__ __launch_bounds__(256) void k_descendant_map(const int32_t* __restrict__ nbr_p, int64_t pitch_p,
+                                                        const uint32_t* __restrict__ perm,
+                                                        const uint64_t* __restrict__ ykeys,
+                                                        const int32_t* __restrict__ parent_of8,
+                                                        const int32_t* __restrict__ parent_of16, int64_t m,
+                                                        int32_t* __restrict__ nbr) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t r = perm[j];
+  const uint64_t key = ykeys[r];
+  const int64_t p = (int64_t)parent_of16[parent_of8[r]] * 8 + (int64_t)((key >> 12) & 7ull);
+  const int o = (int)((key >> 9) & 7ull);
+  int32_t pr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    int kp, op;
+    child_step(o, k, &kp, &op);
+    const int32_t q = nbr_p[(int64_t)kp * pitch_p + p];
+    pr[k] = q < 0 ? -1 : ((q << 3) | op);
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) nbr[(int64_t)k * m + j] = pr[k];
+}
+
+int pcc_descendant_map(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t parent_pitch, const uint32_t* d_perm,
+                       const uint64_t* d_ykeys, const int32_t* d_parent_of8, const int32_t* d_parent_of16, int64_t m,
+                       int32_t* d_nbr) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_descendant_map: null ctx");
+  if (m <= 0) return PCC_OK;
+  PCC_REQUIRE(d_nbr_parent && d_perm && d_ykeys && d_parent_of8 && d_parent_of16 && d_nbr && parent_pitch >= 1 &&
+                  parent_pitch < ((int64_t)1 << 27), PCC_E_ARG, "pcc_descendant_map: bad buffers");
+  PccProfScope prof(ctx, "descendant_map", m, parent_pitch, 0, 27);
+  hipLaunchKernelGGL(k_descendant_map, dim3(nblk(m, 256)), dim3(256), 0, ctx->stream, d_nbr_parent, parent_pitch, d_perm,
+                     d_ykeys, d_parent_of8, d_parent_of16, m, d_nbr);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
 // children given by a stride-2 map (parent_of, nbr8): second lookup through nbr8
 __global__ __launch_bounds__(256) void k_derive_down(const int32_t* __restrict__ nbr_p, int64_t n_par,
                                                      const int32_t* __restrict__ nbr8,

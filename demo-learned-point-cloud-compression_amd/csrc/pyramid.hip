@@ -48,6 +48,16 @@ __global__ void k_up_keys(const uint64_t* __restrict__ keys, int64_t n, int cshi
   ckeys[t] = keys[t >> 3] | ((uint64_t)(t & 7) << cshift);
 }
 
+// the keys of the listed generative children alone (rows[i] = 8p + o): what a pruning keeps of an up stage's 8N
+// candidates, without the 8N keys ever being written
+__global__ void k_up_keys_rows(const uint64_t* __restrict__ keys, int cshift, const uint32_t* __restrict__ rows, int64_t m,
+                               uint64_t* __restrict__ ckeys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t r = rows[i];
+  ckeys[i] = keys[r >> 3] | ((uint64_t)(r & 7u) << cshift);
+}
+
 // Sizes of the whole pyramid above a sorted key set in one pass: with h = the highest bit in which key e differs
 // from key e-1, the two keys have different parents at shift s iff h >= s, so the number of distinct (key >> s) is
 // 1 + #{e >= 1 : h_e >= s}.  Histogram of h (64 bins) + a bin for equal neighbours (duplicate rows).
@@ -273,6 +283,20 @@ extern "C" int pcc_up_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, in
   PCC_REQUIRE(d_keys && d_ckeys, PCC_E_ARG, "pcc_up_coords: null buffers");
   hipLaunchKernelGGL(k_up_keys, dim3(nblk(n * 8, 256)), dim3(256), 0, ctx->stream, d_keys, n,
                      child_shift, d_ckeys);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+extern "C" int pcc_up_coords_rows(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int child_shift, const uint32_t* d_rows,
+                                  int64_t m, uint64_t* d_ckeys) {
+  PCC_REQUIRE(ctx, PCC_E_ARG, "pcc_up_coords_rows: null ctx");
+  PCC_REQUIRE(child_shift >= 0 && child_shift <= 45 && child_shift % 3 == 0, PCC_E_ARG,
+              "pcc_up_coords_rows: child_shift=%d", child_shift);
+  PCC_REQUIRE(n >= 0 && m >= 0 && 8 * n <= 0xFFFFFFFFll, PCC_E_ARG, "pcc_up_coords_rows: bad sizes (n=%lld m=%lld)",
+              (long long)n, (long long)m);
+  if (m == 0) return PCC_OK;
+  PCC_REQUIRE(n > 0 && d_keys && d_rows && d_ckeys, PCC_E_ARG, "pcc_up_coords_rows: null buffers");
+  hipLaunchKernelGGL(k_up_keys_rows, dim3(nblk(m, 256)), dim3(256), 0, ctx->stream, d_keys, child_shift, d_rows, m, d_ckeys);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -290,6 +290,14 @@ class Runtime:
         check(self.lib.pcc_up_coords(self.ctx, _ptr(keys), n, child_shift, _ptr(ckeys)), "pcc_up_coords")
         return ckeys
 
+    def up_coords_rows(self, keys, child_shift, rows):
+        """Keys of the listed generative children (rows[i] = 8 p + o) without the 8 n keys being formed."""
+        m = rows.shape[0]
+        ckeys = self.empty((m,), torch.int64)
+        check(self.lib.pcc_up_coords_rows(self.ctx, _ptr(keys), keys.shape[0], child_shift, _ptr(rows), m, _ptr(ckeys)),
+              "pcc_up_coords_rows")
+        return ckeys
+
     def build_map(self, keys, stride):
         n = keys.shape[0]
         nbr = self.empty((27, n), torch.int32)
@@ -385,12 +393,18 @@ class Runtime:
                                          _ptr(out)), "pcc_linear_gather")
         return out
 
-    def topk_prune(self, logits, offsets, k):
+    def topk_prune(self, logits, offsets, k, with_map=False):
+        """Kept rows (ascending); with_map: also remap [n] = position of a row among the kept ones, or -1."""
         n, nb = logits.shape[0], len(k)
         keep = self.empty((n,), torch.int32)
         offs = (C.c_int64 * (nb + 1))(*offsets)
         ks = (C.c_int64 * nb)(*k)
         nk = C.c_int64(0)
+        if with_map:
+            remap = self.empty((n,), torch.int32)
+            check(self.lib.pcc_topk_prune_map(self.ctx, _ptr(logits), n, nb, offs, ks, _ptr(keep), C.byref(nk), _ptr(remap)),
+                  "pcc_topk_prune_map")
+            return keep[:nk.value], remap
         check(self.lib.pcc_topk_prune(self.ctx, _ptr(logits), n, nb, offs, ks, _ptr(keep), C.byref(nk)),
               "pcc_topk_prune")
         return keep[:nk.value]

@@ -168,6 +168,14 @@ int pcc_down_coords_known(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
  * of h_s and g_s): children key = parent | o << (3*log2(ts/2)), row 8p+o. */
 int pcc_up_coords(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
                   int child_shift, uint64_t* d_ckeys);
+/* the keys of the listed children only: d_ckeys[i] = key of row d_rows[i] = 8p + o of
+ * pcc_up_coords' output (every d_rows[i] < 8n — the caller's contract, as for
+ * pcc_gather_rows), without the 8n keys being written.  What the decoder keeps of
+ * an up stage's candidates (codec_parallel.py:465-472: the pruned tensor's
+ * coordinates). */
+int pcc_up_coords_rows(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
+                       int child_shift, const uint32_t* d_rows, int64_t m,
+                       uint64_t* d_ckeys);
 
 /* ---- rule book (kernel map) and lookup --------------------------------- */
 
@@ -328,6 +336,13 @@ int pcc_linear_gather(pcc_ctx* ctx, const float* d_in, const uint32_t* d_rows,
 int pcc_topk_prune(pcc_ctx* ctx, const float* d_logits, int64_t n, int n_batch,
                    const int64_t* h_offsets, const int64_t* h_k,
                    uint32_t* d_keep_rows, int64_t* h_n_keep);
+/* the same, and d_remap[r] (n entries, nullable) = position of row r in
+ * d_keep_rows, or -1 for a row that is not kept: what pcc_inverse_rows makes of
+ * d_keep_rows, written by the placement itself (the rule book of the pruned
+ * level wants it, pcc_subset_map_up). */
+int pcc_topk_prune_map(pcc_ctx* ctx, const float* d_logits, int64_t n, int n_batch,
+                       const int64_t* h_offsets, const int64_t* h_k,
+                       uint32_t* d_keep_rows, int64_t* h_n_keep, int32_t* d_remap);
 
 /* ---- entropy-model device kernels ------------------------------------- */
 

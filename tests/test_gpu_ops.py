@@ -256,6 +256,13 @@ def test_up_coords(rt, oracle, clouds):
     ck = rt.up_coords(dev(rt, keys.view(np.int64)), 6)
     assert np.array_equal(u64(ck), oracle.up(keys, 8))
     assert np.all(np.diff(u64(ck).astype(np.float64)) > 0)  # children come out Morton-sorted
+    # the keys of listed children alone (what a pruning keeps), without the 8 n keys being formed
+    rng = np.random.default_rng(5)
+    rows = np.sort(rng.choice(8 * len(keys), size=3 * len(keys), replace=False)).astype(np.uint32)
+    rows[:8] = np.arange(8 * len(keys) - 8, 8 * len(keys))      # the last parent's eight, out of order with the rest
+    sub = rt.up_coords_rows(dev(rt, keys.view(np.int64)), 6, dev(rt, rows.view(np.int32)))
+    assert np.array_equal(u64(sub), oracle.up(keys, 8)[rows.astype(np.int64)])
+    assert rt.up_coords_rows(dev(rt, keys.view(np.int64)), 6, dev(rt, rows[:0].view(np.int32))).shape[0] == 0
 
 
 @pytest.mark.parametrize("name,stride", [("rand", 1), ("surf", 1), ("tiny", 1), ("one", 1), ("surf", 8)])
@@ -791,6 +798,11 @@ def test_topk_prune(rt, oracle, case):
     keep = rt.topk_prune(dev(rt, lg), offs, kc)
     ref = oracle.topk(lg, offs, kc)
     assert np.array_equal(host(keep).view(np.uint32), ref)
+    # the same with the rows' positions among the kept ones (-1: not kept) written by the placement
+    keep2, remap = rt.topk_prune(dev(rt, lg), offs, kc, with_map=True)
+    want = np.full(n, -1, np.int32)
+    want[ref.astype(np.int64)] = np.arange(len(ref), dtype=np.int32)
+    assert np.array_equal(host(keep2).view(np.uint32), ref) and np.array_equal(host(remap), want)
 
 
 @pytest.mark.parametrize("case", ["large", "large_ties", "twelve_frames"])
@@ -814,7 +826,12 @@ def test_topk_prune_many_blocks(rt, oracle, case):
         lg = rng.normal(size=n).astype(np.float32)
     k = [int(c * f) for c, f in zip(counts, rng.random(len(counts)))]
     keep = rt.topk_prune(dev(rt, lg), offs, k)
-    assert np.array_equal(host(keep).view(np.uint32), oracle.topk(lg, offs, k))
+    ref = oracle.topk(lg, offs, k)
+    assert np.array_equal(host(keep).view(np.uint32), ref)
+    keep2, remap = rt.topk_prune(dev(rt, lg), offs, k, with_map=True)
+    want = np.full(n, -1, np.int32)
+    want[ref.astype(np.int64)] = np.arange(len(ref), dtype=np.int32)
+    assert np.array_equal(host(keep2).view(np.uint32), ref) and np.array_equal(host(remap), want)
 
 
 # ---------------------------------------------------------------- entropy kernels
