@@ -63,9 +63,15 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row0 = ((int64_t)blockIdx.x * GC_WAVES + wave) * 32;
-  if (row0 >= n_out) return;  // wave-uniform
   const int i = lane & 31, h = lane >> 5;
+  const int64_t n_wg = (n_out + 32 * GC_WAVES - 1) / (32 * GC_WAVES);
+  // resident workgroups (four per CU: pcc_sparse_conv), tiles taken with the grid's stride: the 13.8 KB of weights are
+  // read once per workgroup instead of once per 128 rows (108 MB of L2 reads for 1M rows — as much as the rule book)
+  // and nobody waits at the barrier above again.  One box, 1M rows: one workgroup per tile 87.1 us, 768 / 1024 / 2048
+  // resident workgroups 79.2 / 72.7 / 76.1; a contiguous run of tiles per workgroup instead of the stride 82.4 (1024).
+  for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+  const int64_t row0 = (wg * GC_WAVES + wave) * 32;
+  if (row0 >= n_out) break;  // wave-uniform
 
   f32x16 acc[NT];
 #pragma unroll
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(GC_WAVES * 64) void k_gconv_first(
         const int col = 32 * t + 8 * j + 4 * h;
         if (col < cout) *reinterpret_cast<float4*>(out + g * cout + col) = v;
       }
+  }
   }
 }
 
@@ -704,7 +711,8 @@ static int gen_weights_for(pcc_ctx* ctx, const float* d_w, int k_vol, int cin, i
 // one k_gconv16 launch.  Grid rounded up to a multiple of 8 workgroups: the kernel maps workgroup -> window per XCD.
 // Launches of fewer than kSmallLaunchRows rows (well under one round of 64-row windows on the chip's 4096 wave
 // slots) take 32-row windows: such a launch lasts as long as one window, and a 32-row window is the shorter one
-// (106k rows: 39 us on 64-row windows, 42 on 32-row ones; 26k rows: the other way round).
+// (106k rows: 39 us on 64-row windows, 42 on 32-row ones; 26k rows: the other way round; 408k rows, 6.2 windows per SIMD:
+// 157 us on 64-row windows, 198 on 32-row ones — that launch is not waiting for a last partial round).
 constexpr int64_t kSmallLaunchRows = 100000;
 // PCC_CONV_WIDE_ROWS=1 in the environment (read once): every launch takes the 64-bit row arithmetic that tensors of
 // 2^25 rows and more need — how the tests reach that form without a 4-GB tensor.
@@ -818,7 +826,8 @@ static int sparse_conv_impl(pcc_ctx* ctx, const float* d_in, int64_t n_in, const
   } else if (!sib && !force_scalar() && (uintptr_t)d_in % 16 == 0 && (uintptr_t)d_out % 16 == 0 && cin == 4 &&
              cout % 16 == 0 && cout <= 128) {
     PccProfScope prof(ctx, "sparse_conv", n_out, cin, cout, k_vol);
-    const dim3 grid(nblk(n_out, 32 * GC_WAVES)), block(GC_WAVES * 64);
+    const unsigned full = nblk(n_out, 32 * GC_WAVES), resident = (unsigned)convT16_waves() / 2;   // four workgroups per CU
+    const dim3 grid(resident < full ? resident : full), block(GC_WAVES * 64);
 #define PCC_FIRST(NT_)                                                                                                          \
   if (cout == 32 * NT_)                                                                                                         \
     hipLaunchKernelGGL((k_gconv_first<NT_, true>), grid, block, 0, st, d_in, d_nbr, k_vol, nbr_pitch, n_out, d_w, d_bias, relu, \
