@@ -269,6 +269,11 @@ struct pcc_codec {
   DevPool pool;
   Pinned pin_keys, pin_occ, pin_zsym, pin_ysym, pin_yidx, pin_flag, pin_dec, pin_up;
   hipStream_t up_stream = nullptr;     // host frames cross PCIe on this stream while the compute stream sorts (encode_gop_impl)
+  // container version 1: the latent's octree kernel and the z string's coder run on a second stream (with a context
+  // of its own: the operators take their scratch from their context's arena) beside h_a / h_s, whose launches leave
+  // the chip all but empty (encode_gop_impl)
+  hipStream_t side_stream = nullptr;
+  pcc_ctx* side_ctx = nullptr;
   hipEvent_t up_done = nullptr;
   // events of a call (symbol pieces, geometry slot): created once, handed out again by every call (creating and
   // destroying half a dozen per GOP is host time on the path)
@@ -514,6 +519,16 @@ struct View {
   uint32_t* perm = nullptr;
   int64_t n = 0;
 };
+
+int side_of(pcc_codec* cd, pcc_ctx** out) {
+  if (!cd->side_ctx) {
+    if (!cd->side_stream) PCC_HIP(hipStreamCreateWithFlags(&cd->side_stream, hipStreamNonBlocking));
+    cd->side_ctx = pcc_create(cd->device, cd->side_stream);
+    if (!cd->side_ctx) return PCC_E_HIP;
+  }
+  *out = cd->side_ctx;
+  return PCC_OK;
+}
 
 // an event of the codec's pool for this call (cd->events_used is reset where the call resets the device pool)
 int call_event(pcc_codec* cd, hipEvent_t* out) {
@@ -958,6 +973,8 @@ extern "C" void pcc_codec_destroy(pcc_codec* cd) {
     (void)hipStreamSynchronize(cd->up_stream);
     (void)hipStreamDestroy(cd->up_stream);
   }
+  if (cd->side_ctx) pcc_destroy(cd->side_ctx);   // synchronises its stream
+  if (cd->side_stream) (void)hipStreamDestroy(cd->side_stream);
   if (cd->up_done) (void)hipEventDestroy(cd->up_done);
   for (hipEvent_t e : cd->events) (void)hipEventDestroy(e);
   for (Pinned* p : {&cd->pin_keys, &cd->pin_occ, &cd->pin_zsym, &cd->pin_ysym, &cd->pin_yidx, &cd->pin_flag, &cd->pin_dec,
@@ -1106,6 +1123,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   // ... and so are its colour uploads: a call that left early (duplicate coordinates, a coordinate out of range) may have
   // returned with DMAs of cd->up_stream still writing into pool memory
   if (cd->up_stream) PCC_HIP(hipStreamSynchronize(cd->up_stream));
+  if (cd->side_stream) PCC_HIP(hipStreamSynchronize(cd->side_stream));   // likewise
   cd->pool.reset();
   cd->events_used = 0;
   cd->sets.clear();
@@ -1268,10 +1286,14 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   hipEvent_t geo_ev = nullptr;
   std::vector<int64_t> geo_cap((size_t)n_frames, 0);
   constexpr int kGeoCounts = 20;  // uint32 per frame in the counts block (depth + 1 <= 17 used)
-  auto geometry_device_half = [&]() -> int {
+  bool geo_small = (int)root_keys.size() == 2 * n_frames;
+  for (int f = 0; f < n_frames; ++f) geo_small &= (*yoffs)[f + 1] - (*yoffs)[f] <= pcc_octree_small_max();
+  bool geo_queued = false;
+  auto geometry_device_half = [&](pcc_ctx* gctx) -> int {   // gctx: where the asynchronous form queues its kernels
+    if (geo_queued) return PCC_OK;
+    geo_queued = true;
     const double tg = now_s();
-    bool small = (int)root_keys.size() == 2 * n_frames;
-    for (int f = 0; f < n_frames; ++f) small &= (*yoffs)[f + 1] - (*yoffs)[f] <= pcc_octree_small_max();
+    const bool small = geo_small;
     if (small) {
       int64_t cap_total = 0;
       for (int f = 0; f < n_frames; ++f) {
@@ -1295,10 +1317,10 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         if (g.n == 0) continue;
         // the kernel writes its (small) output straight into the pinned host buffers — they are device-accessible —
         // so the slot needs no transfer of its own
-        PCC_TRY(pcc_octree_small_async(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, cd->pin_occ.p + g.occ_off, geo_cap[f],
+        PCC_TRY(pcc_octree_small_async(gctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, cd->pin_occ.p + g.occ_off, geo_cap[f],
                                        (uint32_t*)cd->pin_keys.p + kGeoCounts * f));
       }
-      PCC_HIP(hipEventRecord(geo_ev, st));
+      PCC_HIP(hipEventRecord(geo_ev, gctx->stream));
       geo_async = true;
       geo_dev_s = now_s() - tg;
       return PCC_OK;
@@ -1363,6 +1385,21 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     return PCC_OK;
   };
 
+  // Container version 1 codes its strings on the GPU; what does not lie on the way to them runs on the codec's second
+  // stream: the octree kernel of the latents here — one workgroup, 58 us — beside h_a, the z string's coder (step 3)
+  // beside h_s.  Both had been queued in the compute stream, which they held up for their whole length.
+  const bool v1 = cd->container_version == 1;  // y / z strings coded on the GPU (rans_gpu.hip), flagged container
+  // (same box, 2 x 30 steps each way: 217.3 / 212.2 frames/s with everything on the compute stream, 222.2 / 224.2 so)
+  pcc_ctx* side = nullptr;
+  if (v1) PCC_TRY(side_of(cd, &side));
+  if (side && geo_small) {
+    hipEvent_t ev_y;
+    PCC_TRY(call_event(cd, &ev_y));
+    PCC_HIP(hipEventRecord(ev_y, st));
+    PCC_HIP(hipStreamWaitEvent(side->stream, ev_y, 0));
+    PCC_TRY(geometry_device_half(side));
+  }
+
   // ---- step 2: hyper analysis h_a
   t0 = now_s();
   Feat z;
@@ -1380,7 +1417,6 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   View zv;
   PCC_TRY(view_of(cd, z.cs, &zv));
   Feat z_hat;
-  const bool v1 = cd->container_version == 1;  // y / z strings coded on the GPU (rans_gpu.hip), flagged container
   int32_t* zsym_dev = nullptr;
   {
     CODEC_ALLOC(zs_f, float, std::max<int64_t>(nz, 1) * cz);
@@ -1396,6 +1432,30 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     float* zf;
     PCC_TRY(rows_to_tensor(cd, zv, zhat_rows, cz, &zf));
     z_hat = {z.cs, zf, cz};
+  }
+  // version 1: room of the coded strings in pinned memory (first attempt: 6 bytes per symbol; the coder's own first
+  // attempt holds 1.5 words per symbol), and the z string's coder queued on the second stream
+  const int64_t per_y = (int64_t)cy * ny, nzs = (int64_t)cz * nz;
+  int64_t cap_y = 0, cap_z = 0;
+  long long* d_lens = nullptr;
+  hipEvent_t z_done = nullptr;
+  if (v1) {
+    PCC_REQUIRE(cd->gc_dev && cd->eb_dev, PCC_E_ARG, "pcc_encode_gop: container version 1 without device CDF tables");
+    cap_y = std::min<int64_t>(pcc_rans_dev_bound(per_y), (6 * per_y + 65536) / 4 * 4);
+    cap_z = std::min<int64_t>(pcc_rans_dev_bound(nzs), (6 * nzs + 65536) / 4 * 4);
+    PCC_TRY(cd->pin_ysym.ensure((size_t)cap_y * n_q + (size_t)cap_z + 256));
+    d_lens = (long long*)cd->pool.alloc(sizeof(long long) * (size_t)(n_q + 1));
+    if (!d_lens) return PCC_E_NOMEM;
+    if (side) {
+      hipEvent_t ev_z;
+      PCC_TRY(call_event(cd, &ev_z));
+      PCC_TRY(call_event(cd, &z_done));
+      PCC_HIP(hipEventRecord(ev_z, st));
+      PCC_HIP(hipStreamWaitEvent(side->stream, ev_z, 0));
+      PCC_TRY(pcc_rans_encode_dev_async(side, cd->eb_dev, zsym_dev, nullptr, std::max<int64_t>(nz, 1), nzs, 1,
+                                        cd->pin_ysym.p + (size_t)cap_y * n_q, cap_z, d_lens + n_q, 0));
+      PCC_HIP(hipEventRecord(z_done, side->stream));
+    }
   }
   // host half of the geometry slot + the z string (codec_pipeline.py:294-317): run by this thread next to the y coders
   std::vector<std::vector<uint8_t>> blobs((size_t)n_frames);
@@ -1425,7 +1485,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     return PCC_OK;
   };
   auto side_streams = [&]() -> int {
-    PCC_TRY(geometry_device_half());
+    PCC_TRY(geometry_device_half(ctx));
     PCC_TRY(geometry_finish());
     double t = now_s();
     std::vector<int32_t> idx((size_t)nz * cz);
@@ -1453,29 +1513,28 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     // Container version 1: symbols and indexes stay in HBM, the Q y streams and the z stream are coded by the GPU's
     // interleaved coder behind the quantiser, and only the finished streams cross PCIe.  The geometry slots (device
     // half + host occupancy coder) follow in the stream / on this thread as in version 0.
-    PCC_REQUIRE(cd->gc_dev && cd->eb_dev, PCC_E_ARG, "pcc_encode_gop: container version 1 without device CDF tables");
     float* params;
     PCC_TRY(h_s_out_at(cd, gp, y.cs, yv, &params));
     float* scale_d;
     PCC_TRY(scale_rows_dev(cd, 0, h_q, n_q, &scale_d));
     const Tensor* tab = find(cd, "gaussian_conditional.scale_table");
     PCC_REQUIRE(tab, PCC_E_ARG, "pcc_encode_gop: gaussian_conditional tables missing");
-    const int64_t per = (int64_t)cy * ny, tot = per * n_q, nzs = (int64_t)cz * nz;
+    const int64_t per = per_y, tot = per * n_q;
     CODEC_ALLOC(sym32, int32_t, std::max<int64_t>(tot, 1));
     CODEC_ALLOC(idx8, uint8_t, std::max<int64_t>(tot, 1));
     if (ny > 0)
       PCC_TRY(pcc_gaussian_quant_dev(ctx, ys_f, params, ny, cy, scale_d, n_q, cd->dev["gaussian_conditional.scale_table"],
                                      (int)tab->dims[0], sym32, idx8));
-    CODEC_ALLOC(d_lens, long long, n_q + 1);
     PCC_TRY(cd->pin_flag.ensure(8 * 65 + 64));
     long long* h_lens = (long long*)cd->pin_flag.p;
     uint8_t *ystreams = nullptr, *zstream = nullptr;
-    int64_t cap_y = 0, cap_z = 0;
-    PCC_TRY(geometry_device_half());  // queued in front of the coder kernels: its output is on the host while they run
+    PCC_TRY(geometry_device_half(ctx));  // (unless it runs on the second stream already) in front of the coder kernels: its output is on the host while they run
     for (int attempt = 0; attempt < 2; ++attempt) {
-      // attempt 0: 6 bytes per symbol of room (the coder's own first attempt holds 1.5 words per symbol); attempt 1: the bound
-      cap_y = attempt == 0 ? std::min<int64_t>(pcc_rans_dev_bound(per), (6 * per + 65536) / 4 * 4) : pcc_rans_dev_bound(per);
-      cap_z = attempt == 0 ? std::min<int64_t>(pcc_rans_dev_bound(nzs), (6 * nzs + 65536) / 4 * 4) : pcc_rans_dev_bound(nzs);
+      // attempt 0: the room reserved above; attempt 1: the bound
+      if (attempt == 1) {
+        cap_y = pcc_rans_dev_bound(per);
+        cap_z = pcc_rans_dev_bound(nzs);
+      }
       // the packing kernels write the finished streams straight into pinned host memory (device-visible): they cross PCIe
       // as they are written, and the one synchronisation for their lengths is also the one for their bytes
       // (same box, three interleaved passes against device buffers + four copies + a second synchronisation: encode
@@ -1484,8 +1543,11 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       ystreams = cd->pin_ysym.p;
       zstream = cd->pin_ysym.p + (size_t)cap_y * n_q;
       PCC_TRY(pcc_rans_encode_dev_async(ctx, cd->gc_dev, sym32, idx8, 1, per, n_q, ystreams, cap_y, d_lens, attempt));
-      PCC_TRY(pcc_rans_encode_dev_async(ctx, cd->eb_dev, zsym_dev, nullptr, std::max<int64_t>(nz, 1), nzs, 1, zstream, cap_z,
-                                        d_lens + n_q, attempt));
+      if (attempt == 0 && z_done)   // coded on the second stream since step 3
+        PCC_HIP(hipStreamWaitEvent(st, z_done, 0));
+      else
+        PCC_TRY(pcc_rans_encode_dev_async(ctx, cd->eb_dev, zsym_dev, nullptr, std::max<int64_t>(nz, 1), nzs, 1, zstream, cap_z,
+                                          d_lens + n_q, attempt));
       PCC_HIP(hipMemcpyAsync(h_lens, d_lens, (size_t)(n_q + 1) * 8, hipMemcpyDeviceToHost, st));
       if (attempt == 0) PCC_TRY(geometry_finish());   // the occupancy coder of this thread runs while the GPU codes
       PCC_HIP(hipStreamSynchronize(st));

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for g in 100000 500000 2000000; do echo "PCC_SMALL_ROWS=$g"; PCC_SMALL_ROWS=$g python3 tools/bench_conv.py --cases stride2,stride1 2>&1 | grep -E "conv " ; done
-python3 tools/bench_first.py 2>&1 | grep "first layer"
+timeout -k 10 600 python -m pytest tests/test_gpu_codec.py tests/test_gpu_rans.py tests/test_gpu_cabi.py -m gpu -x -q > gpurun_out/r04j_tests.log 2>&1; rc=$?
+tail -3 gpurun_out/r04j_tests.log
+[ $rc -eq 0 ] || exit $rc
+STEPS=30 bash tools/ab_env.sh PCC_SIDE_STREAM 0 1 2>&1 | grep -v "^    " | tee gpurun_out/r04j_ab_side.txt
