@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_codec.py tests/test_gpu_rans.py tests/test_gpu_cabi.py -m gpu -x -q > gpurun_out/r04j_tests.log 2>&1; rc=$?
-tail -3 gpurun_out/r04j_tests.log
-[ $rc -eq 0 ] || exit $rc
-STEPS=30 bash tools/ab_env.sh PCC_SIDE_STREAM 0 1 2>&1 | grep -v "^    " | tee gpurun_out/r04j_ab_side.txt
+STEPS=30 bash tools/ab_env.sh PCC_XYZ16 0 1 2>&1 | grep -v "^    " | tee gpurun_out/r04k_ab_xyz16.txt
