@@ -1769,6 +1769,7 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   PCC_HIP(hipSetDevice(cd->device));
   PCC_TRY(pcc_sync(ctx));
   if (cd->up_stream) PCC_HIP(hipStreamSynchronize(cd->up_stream));   // an encode on this codec that left early (see there)
+  if (cd->side_stream) PCC_HIP(hipStreamSynchronize(cd->side_stream));
   cd->pool.reset();
   cd->events_used = 0;
   cd->sets.clear();
