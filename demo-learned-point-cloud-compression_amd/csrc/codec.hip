@@ -220,6 +220,14 @@ struct PccWorkers {
     }
     cv_job.notify_all();
   }
+  void wait_range(int lo, int hi) {   // workers lo .. hi - 1 only (others may hold longer jobs)
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] {
+      for (int i = lo; i < hi && i < (int)busy.size(); ++i)
+        if (busy[i]) return false;
+      return true;
+    });
+  }
   void wait_all() {
     std::unique_lock<std::mutex> lk(m);
     cv_done.wait(lk, [&] {
@@ -1274,7 +1282,15 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     int depth;
     int32_t origin[3];
     std::vector<int64_t> level_n;
-    std::vector<uint8_t> v2;   // a frame above PCC_OCTREE_V2_MIN_LEAVES leaves: its finished blob (octree2.hip)
+    std::vector<uint8_t> v2;   // a frame whose blob the device half finished: version 2 (octree2.hip), or version 3 on the synchronous path
+    // blob version 3 (PCC_OCTREE_V3_MIN_LEAVES leaves and more): the frame's leaves in K parts under the frame's root
+    struct Part {
+      int64_t n = 0, occ_off = 0, nodes = 0;
+      std::vector<int64_t> level_n;
+    };
+    int K = 1;
+    int counts_at = 0;   // first counts block of the frame (kGeoCounts words each, one per part)
+    std::vector<Part> parts;
   };
   std::vector<FrameGeo> geo((size_t)n_frames);
   double geo_dev_s = 0;
@@ -1296,6 +1312,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     const bool small = geo_small;
     if (small) {
       int64_t cap_total = 0;
+      int n_blocks = 0;
       for (int f = 0; f < n_frames; ++f) {
         FrameGeo& g = geo[f];
         g.n = (*yoffs)[f + 1] - (*yoffs)[f];
@@ -1303,22 +1320,29 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         g.occ_off = cap_total;
         g.occ_len = 0;
         g.origin[0] = g.origin[1] = g.origin[2] = 0;
+        g.K = g.n >= PCC_OCTREE_V3_MIN_LEAVES ? pcc_octree_parts_for(g.n) : 1;
+        g.counts_at = n_blocks;
+        n_blocks += g.K;
         if (g.n > 0) {
           octree_root(root_keys[2 * f], root_keys[2 * f + 1], 9, &g.depth, g.origin);
-          geo_cap[f] = (g.n * g.depth + 255) & ~(int64_t)255;
+          geo_cap[f] = (g.n * g.depth + 4 * g.K + 4 + 255) & ~(int64_t)255;
           cap_total += geo_cap[f];
         }
       }
       PCC_TRY(cd->pin_occ.ensure((size_t)std::max<int64_t>(cap_total, 1)));
-      PCC_TRY(cd->pin_keys.ensure((size_t)kGeoCounts * 4 * n_frames));
+      PCC_TRY(cd->pin_keys.ensure((size_t)kGeoCounts * 4 * n_blocks));
       if (!geo_ev) PCC_TRY(call_event(cd, &geo_ev));
       for (int f = 0; f < n_frames; ++f) {
         FrameGeo& g = geo[f];
         if (g.n == 0) continue;
         // the kernel writes its (small) output straight into the pinned host buffers — they are device-accessible —
         // so the slot needs no transfer of its own
-        PCC_TRY(pcc_octree_small_async(gctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, cd->pin_occ.p + g.occ_off, geo_cap[f],
-                                       (uint32_t*)cd->pin_keys.p + kGeoCounts * f));
+        if (g.K > 1)
+          PCC_TRY(pcc_octree_parts_async(gctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, g.K, cd->pin_occ.p + g.occ_off,
+                                         geo_cap[f], (uint32_t*)cd->pin_keys.p + kGeoCounts * g.counts_at, kGeoCounts));
+        else
+          PCC_TRY(pcc_octree_small_async(gctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, cd->pin_occ.p + g.occ_off, geo_cap[f],
+                                         (uint32_t*)cd->pin_keys.p + kGeoCounts * g.counts_at));
       }
       PCC_HIP(hipEventRecord(geo_ev, gctx->stream));
       geo_async = true;
@@ -1355,6 +1379,14 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
         g.v2.resize((size_t)len2);
         continue;
       }
+      if (g.n >= PCC_OCTREE_V3_MIN_LEAVES) {   // blob version 3 on this (synchronous) path: the one-call form
+        const int64_t cap3 = 4096 + 3 * g.n * g.depth;
+        int64_t len3 = 0;
+        g.v2.resize((size_t)cap3);
+        PCC_TRY(pcc_octree_encode_version(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, 3, g.v2.data(), cap3, &len3));
+        g.v2.resize((size_t)len3);
+        continue;
+      }
       g.level_n.assign((size_t)g.depth, 0);
       PCC_TRY(pcc_octree_levels(ctx, y.cs->keys + (*yoffs)[f], g.n, 9, g.depth, occ + g.occ_off, g.n * g.depth,
                                 g.level_n.data()));
@@ -1373,9 +1405,31 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
     for (int f = 0; f < n_frames; ++f) {
       FrameGeo& g = geo[f];
       if (g.n == 0) continue;
+      if (g.K > 1) {   // parts: leaf counts first (they place the parts' bytes), then the level counts of each
+        g.parts.assign((size_t)g.K, FrameGeo::Part());
+        int64_t start = 0;
+        for (int k = 0; k < g.K; ++k) {
+          const uint32_t* c = hc + kGeoCounts * (g.counts_at + k);
+          FrameGeo::Part& pt = g.parts[(size_t)k];
+          pt.n = (int64_t)c[g.depth];
+          pt.occ_off = g.occ_off + (int64_t)((((uint64_t)start * (uint64_t)g.depth) + 3) & ~(uint64_t)3) + 4 * k;
+          pt.level_n.assign((size_t)g.depth, 0);
+          for (int L = 0; L < g.depth && pt.n > 0; ++L) {
+            pt.level_n[L] = (int64_t)c[L];
+            pt.nodes += pt.level_n[L];
+          }
+          PCC_REQUIRE(start + pt.n <= g.n && pt.nodes <= pt.n * g.depth && (pt.n == 0 || pt.level_n[0] == 1), PCC_E_ARG,
+                      "pcc_encode_gop: octree of frame %d, part %d: %lld leaves behind %lld of %lld, %lld nodes", f, k,
+                      (long long)pt.n, (long long)start, (long long)g.n, (long long)pt.nodes);
+          start += pt.n;
+        }
+        PCC_REQUIRE(start == g.n, PCC_E_ARG, "pcc_encode_gop: octree of frame %d: its parts hold %lld of %lld leaves", f,
+                    (long long)start, (long long)g.n);
+        continue;
+      }
       g.level_n.assign((size_t)g.depth, 0);
       for (int L = 0; L < g.depth; ++L) {
-        g.level_n[L] = (int64_t)hc[kGeoCounts * f + L];
+        g.level_n[L] = (int64_t)hc[kGeoCounts * g.counts_at + L];
         g.occ_len += g.level_n[L];
       }
       PCC_REQUIRE(g.level_n[0] == 1 && g.occ_len <= g.n * g.depth, PCC_E_ARG,
@@ -1464,6 +1518,7 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
   const Tensor *eb_cdf = find(cd, "entropy_bottleneck.quantized_cdf"), *eb_len = find(cd, "entropy_bottleneck.cdf_length"),
                *eb_off = find(cd, "entropy_bottleneck.offset");
   PCC_REQUIRE(eb_cdf && eb_len && eb_off, PCC_E_ARG, "pcc_encode_gop: entropy_bottleneck tables missing");
+  const bool geo_threads = v1;   // version 0: the codec's threads are coding the y strings while this runs
   auto geometry_finish = [&]() -> int {
     PCC_TRY(geometry_arrived());
     const double t = now_s();
@@ -1471,6 +1526,43 @@ static int encode_gop_impl(pcc_codec* cd, const int32_t* d_coords, const float* 
       FrameGeo& g = geo[f];
       if (!g.v2.empty()) {
         blobs[f].swap(g.v2);
+        continue;
+      }
+      if (g.K > 1 && !g.parts.empty()) {   // blob version 3: the parts' coders side by side where threads are free
+        std::vector<std::vector<uint8_t>> pb((size_t)g.K);
+        std::vector<int> prc((size_t)g.K, PCC_OK);
+        std::vector<std::string> perr((size_t)g.K);
+        const int64_t zero = 0;
+        const int32_t org0[3] = {0, 0, 0};
+        auto pack_part = [&](int k) {
+          const FrameGeo::Part& pt = g.parts[(size_t)k];
+          pb[(size_t)k].resize((size_t)(64 + 2 * pt.nodes + 16));
+          int64_t len = 0;
+          prc[(size_t)k] = pcc_octree_pack(pt.n ? cd->pin_occ.p + pt.occ_off : nullptr, pt.n ? pt.level_n.data() : &zero,
+                                           pt.n ? g.depth : 0, pt.n, pt.n ? g.origin : org0, pb[(size_t)k].data(),
+                                           (int64_t)pb[(size_t)k].size(), &len);
+          if (prc[(size_t)k] != PCC_OK) perr[(size_t)k] = pcc_last_error();
+          pb[(size_t)k].resize((size_t)(prc[(size_t)k] == PCC_OK ? len : 0));
+        };
+        if (geo_threads) {   // container version 1: the codec's threads have nothing else to do at this point
+          cd->workers.ensure(g.K - 1);
+          for (int k = 1; k < g.K; ++k) cd->workers.run(k - 1, [&pack_part, k]() { pack_part(k); });
+          pack_part(0);
+          cd->workers.wait_all();
+        } else {
+          for (int k = 0; k < g.K; ++k) pack_part(k);
+        }
+        for (int k = 0; k < g.K; ++k)
+          if (prc[(size_t)k] != PCC_OK) {
+            pcc_set_error("pcc_encode_gop (geometry, frame %d part %d): %s", f, k, perr[(size_t)k].c_str());
+            return prc[(size_t)k];
+          }
+        int64_t tot = 64 + 4 * g.K;
+        for (const auto& b : pb) tot += (int64_t)b.size();
+        blobs[f].resize((size_t)tot);
+        int64_t len = 0;
+        PCC_TRY(pcc_octree_join_parts(g.depth, g.origin, g.n, pb.data(), g.K, blobs[f].data(), tot, &len));
+        blobs[f].resize((size_t)len);
         continue;
       }
       const int64_t cap = 64 + 2 * g.occ_len + 16;
@@ -1937,41 +2029,146 @@ static int decode_gop_impl(pcc_codec* cd, const uint8_t* h_in, int64_t len, pcc_
   int n_batch = 0;
   int64_t n16 = 0, n32 = 0;
   std::vector<std::vector<int32_t>> fpts((size_t)n_frames);
+  // The rows (frame, 8 x, 8 y, 8 z) of all latents, in pinned memory for the upload.  ny is the sum of the announced
+  // counts, bounded above; a frame's rows are written only by what its stream decoded.
+  PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
+  int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
+  std::vector<int64_t> frow((size_t)n_frames + 1, 0);
+  for (int f = 0; f < n_frames; ++f) frow[(size_t)f + 1] = frow[(size_t)f] + fn[f];
+  // blob version 3: the parts of all frames decoded side by side on the codec's threads (worker 0 may hold the z job:
+  // workers 1 .. take parts, this thread takes the first of every round).  A job decodes its part and writes its rows
+  // itself — the part's leaf count is in its header and the part's decoder holds the stream to it —, so what is left
+  // for this thread is the check of the parts against each other.
+  struct PartJob {
+    int f, k;
+    const uint8_t* p;
+    int64_t len, n, row0;
+    int32_t org[3];
+    PccOctPart out;
+    bool out_of_range = false;
+    int rc = PCC_OK;
+    std::string err;
+  };
+  std::vector<PartJob> pjobs;
+  std::vector<int> fpart0((size_t)n_frames, -1), fparts((size_t)n_frames, 0);
+  for (int f = 0; f < n_frames; ++f) {
+    if (fn[f] == 0 || slots[f].p[1] != 3) continue;
+    int K = 0;
+    const uint8_t* pp[16];
+    int64_t pl[16];
+    PCC_TRY(pcc_octree_parts(slots[f].p, slots[f].len, &K, pp, pl));   // the parts' counts add up to fn[f]
+    int32_t org[3];
+    PCC_TRY(pcc_octree_peek(slots[f].p, slots[f].len, nullptr, nullptr, org));
+    fpart0[f] = (int)pjobs.size();
+    fparts[f] = K;
+    int64_t row = frow[(size_t)f];
+    for (int k = 0; k < K; ++k) {
+      pjobs.emplace_back();
+      PartJob& pj = pjobs.back();
+      pj.f = f;
+      pj.k = k;
+      pj.p = pp[k];
+      pj.len = pl[k];
+      PCC_TRY(pcc_octree_peek(pp[k], pl[k], &pj.n, nullptr, nullptr));
+      pj.row0 = row;
+      memcpy(pj.org, org, sizeof(org));
+      row += pj.n;
+    }
+  }
+  if (!pjobs.empty()) {
+    constexpr int kPartThreads = 8;
+    auto run_job = [&pjobs, yc_h](int j) {
+      PartJob& pj = pjobs[(size_t)j];
+      pj.rc = pcc_octree_unpack_part(pj.p, pj.len, &pj.out);
+      if (pj.rc != PCC_OK) {
+        pj.err = pcc_last_error();
+        return;
+      }
+      if ((int64_t)pj.out.cells.size() != pj.n) {   // (the part's decoder has checked this against the part's header)
+        pj.rc = PCC_E_STREAM;
+        pj.err = "part decoded another number of leaves than its header says";
+        return;
+      }
+      int32_t xyz[3 * 64];
+      bool bad = false;
+      for (int64_t i0 = 0; i0 < pj.n; i0 += 64) {
+        const int64_t m = std::min<int64_t>(64, pj.n - i0);
+        pcc_octree_cells_to_points(pj.out.cells.data() + i0, m, pj.org, xyz);
+        int32_t* dst = yc_h + 4 * (pj.row0 + i0);
+        for (int64_t i = 0; i < m; ++i) {
+          const int32_t x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+          bad |= (x < -4096) | (x > 4095) | (y < -4096) | (y > 4095) | (z < -4096) | (z > 4095);
+          dst[4 * i] = pj.f;
+          dst[4 * i + 1] = x * 8;
+          dst[4 * i + 2] = y * 8;
+          dst[4 * i + 3] = z * 8;
+        }
+      }
+      pj.out_of_range = bad;
+    };
+    cd->workers.ensure(kPartThreads);
+    const int nj = (int)pjobs.size();
+    for (int j0 = 0; j0 < nj; j0 += kPartThreads) {
+      const int j1 = std::min(nj, j0 + kPartThreads);
+      for (int j = j0 + 1; j < j1; ++j) cd->workers.run(j - j0, [&run_job, j]() { run_job(j); });
+      run_job(j0);
+      cd->workers.wait_range(1, kPartThreads);
+    }
+    for (const PartJob& pj : pjobs)
+      if (pj.rc != PCC_OK) {
+        pcc_set_error("pcc_decode_gop (geometry, frame %d part %d): %s", pj.f, pj.k, pj.err.c_str());
+        return pj.rc;
+      }
+  }
+  bool out_of_range = false;
   for (int f = 0; f < n_frames; ++f) {
     if (fn[f] == 0) continue;
     int64_t level_n[16];
-    if (slots[f].p[1] == 2) {   // blob version 2: decoded by the GPU; fn[f] has passed the plausibility checks above
-      int64_t n2 = 0;
-      fpts[f].resize((size_t)(3 * fn[f]));
-      PCC_TRY(pcc_octree2_decode(ctx, slots[f].p, slots[f].len, nullptr, fpts[f].data(), fn[f], &n2, level_n));
+    if (slots[f].p[1] == 3) {   // the parts against each other: order, counts; the rows are written
+      for (int L = 0; L < 16; ++L) level_n[L] = 0;
+      bool any = false;
+      uint64_t last = 0;
+      int64_t total = 0;
+      for (int k = 0; k < fparts[f]; ++k) {
+        const PartJob& pj = pjobs[(size_t)(fpart0[f] + k)];
+        out_of_range |= pj.out_of_range;
+        if (pj.out.cells.empty()) continue;
+        PCC_REQUIRE(!any || (pj.out.cells.front() >> 6) > (last >> 6), PCC_E_STREAM,
+                    "pcc_decode_gop: frame %d: part %d begins inside or in front of the cell the part before it ends in", f, k);
+        any = true;
+        last = pj.out.cells.back();
+        total += (int64_t)pj.out.cells.size();
+        for (int L = 0; L < 16; ++L) level_n[L] += pj.out.level_n[L];
+      }
+      PCC_REQUIRE(total == fn[f], PCC_E_STREAM, "pcc_decode_gop: frame %d decoded %lld points, announced %lld", f, (long long)total,
+                  (long long)fn[f]);
     } else {
-      PCC_TRY(pcc_octree_unpack_vec(slots[f].p, slots[f].len, &fpts[f], level_n));
+      if (slots[f].p[1] == 2) {   // blob version 2: decoded by the GPU; fn[f] has passed the plausibility checks above
+        int64_t n2 = 0;
+        fpts[f].resize((size_t)(3 * fn[f]));
+        PCC_TRY(pcc_octree2_decode(ctx, slots[f].p, slots[f].len, nullptr, fpts[f].data(), fn[f], &n2, level_n));
+      } else {
+        PCC_TRY(pcc_octree_unpack_vec(slots[f].p, slots[f].len, &fpts[f], level_n));
+      }
+      PCC_REQUIRE((int64_t)fpts[f].size() == 3 * fn[f], PCC_E_STREAM, "pcc_decode_gop: frame %d decoded %zu points, announced %lld",
+                  f, fpts[f].size() / 3, (long long)fn[f]);
+      const int32_t* pts = fpts[f].data();
+      int32_t* dst = yc_h + 4 * frow[(size_t)f];
+      for (int64_t i = 0; i < fn[f]; ++i) {
+        const int32_t x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        out_of_range |= (x < -4096) | (x > 4095) | (y < -4096) | (y > 4095) | (z < -4096) | (z > 4095);
+        dst[4 * i] = f;
+        dst[4 * i + 1] = x * 8;
+        dst[4 * i + 2] = y * 8;
+        dst[4 * i + 3] = z * 8;
+      }
     }
-    PCC_REQUIRE((int64_t)fpts[f].size() == 3 * fn[f], PCC_E_STREAM, "pcc_decode_gop: frame %d decoded %zu points, announced %lld",
-                f, fpts[f].size() / 3, (long long)fn[f]);
     const int depth = fdepth[f];
     n16 += depth >= 1 ? level_n[depth - 1] : 1;
     n32 += depth >= 2 ? level_n[depth - 2] : 1;
     n_batch = f + 1;
   }
   if (!z_early && !v1) start_z_job();
-  PCC_TRY(cd->pin_keys.ensure((size_t)std::max<int64_t>(ny, 1) * 16));
-  int32_t* yc_h = (int32_t*)cd->pin_keys.p;  // [ny,4]
-  bool out_of_range = false;
-  {
-    int64_t row = 0;
-    for (int f = 0; f < n_frames; ++f) {
-      const int32_t* pts = fpts[f].data();
-      for (int64_t i = 0; i < fn[f]; ++i, ++row) {
-        const int32_t x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        out_of_range |= (x < -4096) | (x > 4095) | (y < -4096) | (y > 4095) | (z < -4096) | (z > 4095);
-        yc_h[4 * row] = f;
-        yc_h[4 * row + 1] = x * 8;
-        yc_h[4 * row + 2] = y * 8;
-        yc_h[4 * row + 3] = z * 8;
-      }
-    }
-  }
   PCC_REQUIRE(!out_of_range && n_batch <= 65535, PCC_E_RANGE, "pcc_decode_gop: decoded coordinate out of range");
   ts[1] = now_s() - t0;
 

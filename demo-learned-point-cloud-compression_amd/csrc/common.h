@@ -106,6 +106,14 @@ int pcc_descendant_map(pcc_ctx* ctx, const int32_t* d_nbr_parent, int64_t parent
 int pcc_octree_small_max();
 int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, uint8_t* d_occ,
                            int64_t cap_s, uint32_t* d_counts);
+// parts of a blob of version 3 for n leaves: min(8, n / 4096), at least 2 (the rule oracle/pcc_oracle.c states)
+static inline int pcc_octree_parts_for(int64_t n) {
+  const int64_t k = n / 4096;
+  return (int)(k > 8 ? 8 : (k < 2 ? 2 : k));
+}
+// octree.hip: the same for blob version 3 — K parts of the frame's leaves under the frame's root, one workgroup each
+int pcc_octree_parts_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, int K, uint8_t* d_occ,
+                           int64_t cap_s, uint32_t* d_counts, int counts_stride);
 int pcc_sparse_conv_head_up_perm_rgb(pcc_ctx* ctx, const float* d_in, int64_t n_parents, const int32_t* d_nbr_parent,
                                      int64_t parent_pitch, const float* d_w, const float* d_bias, int relu,
                                      const float* d_head_w, const float* d_head_b, float* d_head_out,

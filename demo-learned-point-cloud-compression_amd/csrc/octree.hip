@@ -44,9 +44,8 @@ __device__ __forceinline__ int oct_lmin(uint64_t prev, uint64_t cur, bool first,
   return depth - (63 - __builtin_clzll(x)) / 3;
 }
 
-__global__ __launch_bounds__(OCT_T) void k_oct_small(const uint64_t* __restrict__ keys, int n, int shift,
-                                                     uint64_t mask, int depth, uint32_t* __restrict__ occ32,
-                                                     int cap, uint32_t* __restrict__ counts) {
+__device__ __forceinline__ void oct_small_body(const uint64_t* __restrict__ keys, int n, int shift, uint64_t mask, int depth,
+                                               uint32_t* __restrict__ occ32, int cap, uint32_t* __restrict__ counts) {
   // Each wave owns a contiguous chunk of leaves in both sweeps, so after the one exchange of per-wave level
   // counts the waves never wait for each other and their loads overlap.
   __shared__ uint32_t s_off[OCT_MAXD + 1];
@@ -173,6 +172,52 @@ __global__ __launch_bounds__(OCT_T) void k_oct_small(const uint64_t* __restrict_
     for (uint32_t j = tid; j < words; j += OCT_T) occ32[j] = s_occ[j];
 }
 
+__global__ __launch_bounds__(OCT_T) void k_oct_small(const uint64_t* __restrict__ keys, int n, int shift,
+                                                     uint64_t mask, int depth, uint32_t* __restrict__ occ32,
+                                                     int cap, uint32_t* __restrict__ counts) {
+  oct_small_body(keys, n, shift, mask, depth, occ32, cap, counts);
+}
+
+// Blob version 3 (octree_host.cpp): the frame's leaves in gridDim.x parts under the frame's root, one workgroup each.
+// Part k = leaves [cut(n k / K), cut(n (k + 1) / K)), cut(t) = the first leaf at or behind t whose grandparent cell
+// (leaf >> 6) differs from its predecessor's (0 for t = 0, n behind the last such leaf).  Its occupancy bytes go to
+// occ + 4-aligned (start * depth) + 4 k — a part has at most (leaves x depth) nodes, so the regions are disjoint and
+// the host finds them from the leaf counts alone —, its level counts and leaf count to counts + stride * k (all zero
+// for an empty part).
+__global__ __launch_bounds__(OCT_T) void k_oct_parts(const uint64_t* __restrict__ keys, int n, int shift, uint64_t mask,
+                                                     int depth, uint8_t* __restrict__ occ, uint32_t* __restrict__ counts,
+                                                     int counts_stride) {
+  __shared__ int s_cut[2];
+  const int K = (int)gridDim.x, k = (int)blockIdx.x, lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {   // wave 0 finds both cuts, 64 candidates at a time
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int t = (int)((int64_t)n * (k + which) / K);
+      int found = t <= 0 ? 0 : n;
+      for (int pos = t; t > 0 && pos < n; pos += 64) {   // wave-uniform
+        const int e = pos + lane;
+        bool hit = false;
+        if (e < n) hit = ((((keys[e] >> shift) & mask) >> 6) != (((keys[e - 1] >> shift) & mask) >> 6));
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+          found = pos + (int)__builtin_ctzll(bal);
+          break;
+        }
+      }
+      if (lane == 0) s_cut[which] = found;
+    }
+  }
+  __syncthreads();
+  const int lo = s_cut[0], hi = s_cut[1];
+  uint32_t* my_counts = counts + (size_t)counts_stride * k;
+  if (hi <= lo) {
+    if (threadIdx.x <= (unsigned)depth) my_counts[threadIdx.x] = 0u;
+    return;
+  }
+  const uint32_t off = (((uint32_t)lo * (uint32_t)depth + 3u) & ~3u) + 4u * (uint32_t)k;
+  oct_small_body(keys + lo, hi - lo, shift, mask, depth, reinterpret_cast<uint32_t*>(occ + off), (hi - lo) * depth + 3, my_counts);
+}
+
 // Internal (codec.hip): the single-workgroup form alone and nothing read back — the levels packed root-first into
 // d_occ (4-byte aligned, cap_s bytes), the node counts of levels 0 .. depth-1 and the leaf count into
 // d_counts[depth + 1].  A total above cap_s leaves d_occ untouched; the caller sees it in the counts.
@@ -187,6 +232,23 @@ int pcc_octree_small_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int 
   const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
   hipLaunchKernelGGL(k_oct_small, dim3(1), dim3(OCT_T), 0, ctx->stream, d_keys, (int)n, key_shift, leaf_mask, depth,
                      (uint32_t*)d_occ, (int)cap_s, d_counts);
+  PCC_CHECK_LAUNCH();
+  return PCC_OK;
+}
+
+// the same for blob version 3: K parts (2 .. 16), d_occ of (n * depth + 4 K + 4) bytes, d_counts of K * counts_stride
+// words (counts_stride >= depth + 1)
+int pcc_octree_parts_async(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int depth, int K, uint8_t* d_occ,
+                           int64_t cap_s, uint32_t* d_counts, int counts_stride) {
+  PCC_REQUIRE(ctx && d_keys && d_occ && d_counts && n >= 2 && n <= (int64_t)OCT_SMALL_MAX * 8 && depth >= 1 && depth <= 16 &&
+                  K >= 2 && K <= 16 && key_shift >= 0 && key_shift % 3 == 0 && key_shift + 3 * depth <= 48 &&
+                  cap_s >= n * depth + 4 * K + 4 && cap_s < ((int64_t)1 << 31) && (uintptr_t)d_occ % 4 == 0 &&
+                  counts_stride >= depth + 1,
+              PCC_E_ARG, "pcc_octree_parts_async: bad argument (n=%lld depth=%d K=%d)", (long long)n, depth, K);
+  PccProfScope prof(ctx, "octree_levels", n, depth, K, 0);
+  const uint64_t leaf_mask = (depth == 16 ? ~0ull >> 16 : ((1ull << (3 * depth)) - 1));
+  hipLaunchKernelGGL(k_oct_parts, dim3((unsigned)K), dim3(OCT_T), 0, ctx->stream, d_keys, (int)n, key_shift, leaf_mask, depth,
+                     d_occ, d_counts, counts_stride);
   PCC_CHECK_LAUNCH();
   return PCC_OK;
 }

@@ -766,9 +766,11 @@ int pcc_octree2_decode(pcc_ctx* ctx, const uint8_t* h_in, int64_t len, int32_t* 
 // ---- C-ABI: the geometry slot, one call each (utils.gpcc_encode / gpcc_decode, shared/utils.py:169-240) -------------
 extern "C" int pcc_octree_encode_version(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n, int key_shift, int version,
                                          uint8_t* h_out, int64_t cap, int64_t* h_len) {
-  PCC_REQUIRE(ctx && h_out && h_len && n >= 0 && (n == 0 || d_keys) && version >= 0 && version <= 2, PCC_E_ARG,
+  PCC_REQUIRE(ctx && h_out && h_len && n >= 0 && (n == 0 || d_keys) && version >= 0 && version <= 3, PCC_E_ARG,
               "pcc_octree_encode: bad argument");
-  if (version == 0) version = n > PCC_OCTREE_V2_MIN_LEAVES ? 2 : 1;
+  if (version == 0) version = n > PCC_OCTREE_V2_MIN_LEAVES ? 2 : (n >= PCC_OCTREE_V3_MIN_LEAVES ? 3 : 1);
+  PCC_REQUIRE(version != 3 || (n >= 2 && n <= 8 * (int64_t)pcc_octree_small_max()), PCC_E_ARG,
+              "pcc_octree_encode: blob version 3 takes 2 .. %lld leaves (n=%lld)", 8 * (long long)pcc_octree_small_max(), (long long)n);
   const int64_t zero = 0;
   const int32_t org0[3] = {0, 0, 0};
   if (n == 0) {
@@ -784,6 +786,46 @@ extern "C" int pcc_octree_encode_version(pcc_ctx* ctx, const uint64_t* d_keys, i
   int32_t origin[3];
   octree_root(ends[0], ends[1], key_shift, &depth, origin);
   if (version == 2) return pcc_octree2_encode(ctx, d_keys, n, key_shift, depth, origin, h_out, cap, h_len);
+  if (version == 3) {   // parts under the frame's root: one workgroup each on the GPU, one after the other on this thread
+    const int K = pcc_octree_parts_for(n);
+    PCC_REQUIRE(n <= (int64_t)K * pcc_octree_small_max() / 2, PCC_E_ARG, "pcc_octree_encode: %lld leaves in %d parts", (long long)n, K);
+    constexpr int kStride = 20;
+    const int64_t cap_occ = n * depth + 4 * K + 4;
+    uint8_t* d_buf = nullptr;
+    PCC_HIP(hipMalloc((void**)&d_buf, (size_t)cap_occ + 256 + (size_t)K * kStride * 4));
+    uint32_t* d_counts = (uint32_t*)(d_buf + (((size_t)cap_occ + 255) & ~(size_t)255));
+    std::vector<uint8_t> occ((size_t)cap_occ);
+    std::vector<uint32_t> counts((size_t)K * kStride);
+    int rc = pcc_octree_parts_async(ctx, d_keys, n, key_shift, depth, K, d_buf, cap_occ, d_counts, kStride);
+    if (rc == PCC_OK && (hipMemcpyAsync(occ.data(), d_buf, (size_t)cap_occ, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                         hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                         hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+      pcc_set_error("pcc_octree_encode: reading the parts back failed");
+      rc = PCC_E_HIP;
+    }
+    (void)hipFree(d_buf);
+    PCC_TRY(rc);
+    std::vector<std::vector<uint8_t>> parts((size_t)K);
+    int64_t start = 0;
+    for (int k = 0; k < K; ++k) {
+      const uint32_t* c = counts.data() + (size_t)k * kStride;
+      const int64_t np = (int64_t)c[depth];
+      std::vector<int64_t> level_n((size_t)depth, 0);
+      int64_t nodes = 0;
+      for (int L = 0; L < depth; ++L) { level_n[(size_t)L] = np ? (int64_t)c[L] : 0; nodes += level_n[(size_t)L]; }
+      PCC_REQUIRE(start + np <= n && nodes <= np * depth, PCC_E_ARG, "pcc_octree_encode: part %d: %lld leaves behind %lld of %lld, %lld nodes",
+                  k, (long long)np, (long long)start, (long long)n, (long long)nodes);
+      const size_t off = ((((size_t)start * depth) + 3) & ~(size_t)3) + 4 * (size_t)k;
+      parts[(size_t)k].resize((size_t)(64 + 2 * nodes + 16));
+      int64_t len = 0;
+      PCC_TRY(pcc_octree_pack(np ? occ.data() + off : nullptr, np ? level_n.data() : &zero, np ? depth : 0, np, np ? origin : org0,
+                              parts[(size_t)k].data(), (int64_t)parts[(size_t)k].size(), &len));
+      parts[(size_t)k].resize((size_t)len);
+      start += np;
+    }
+    PCC_REQUIRE(start == n, PCC_E_ARG, "pcc_octree_encode: the parts hold %lld of %lld leaves", (long long)start, (long long)n);
+    return pcc_octree_join_parts(depth, origin, n, parts.data(), K, h_out, cap, h_len);
+  }
   uint8_t* d_occ = nullptr;
   PCC_HIP(hipMalloc((void**)&d_occ, (size_t)n * depth));
   std::vector<int64_t> level_n((size_t)depth, 0);
@@ -806,7 +848,7 @@ extern "C" int pcc_octree_encode(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n
 }
 
 extern "C" int pcc_octree_blob_version(const uint8_t* h_in, int64_t len) {
-  if (!h_in || len < kHeader || h_in[0] != 'O' || (h_in[1] != 1 && h_in[1] != 2)) {
+  if (!h_in || len < kHeader || h_in[0] != 'O' || h_in[1] < 1 || h_in[1] > 3) {
     pcc_set_error("not an octree blob (len=%lld)", (long long)len);
     return PCC_E_STREAM;
   }
@@ -817,7 +859,7 @@ extern "C" int pcc_octree_decode_ctx(pcc_ctx* ctx, const uint8_t* h_in, int64_t 
                                      int64_t* h_n_points) {
   const int v = pcc_octree_blob_version(h_in, len);
   if (v < 0) return v;
-  if (v == 1) return pcc_octree_decode(h_in, len, h_points, cap_points, h_n_points);
+  if (v != 2) return pcc_octree_decode(h_in, len, h_points, cap_points, h_n_points);   // versions 1 and 3: host decoders
   return pcc_octree2_decode(ctx, h_in, len, nullptr, h_points, cap_points, h_n_points, nullptr);
 }
 

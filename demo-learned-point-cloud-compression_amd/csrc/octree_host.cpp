@@ -8,6 +8,14 @@
 // length-prefixed byte string (codec_pipeline.py:503,510), so the container
 // layout is unchanged.
 //
+// Blob version 3 (round 4): the frame's leaves in K parts, each a complete version-1 blob under the FRAME's root cube,
+// coded and decoded side by side (the serial decoder of a 26k-leaf latent was 0.21 ms at the head of every decode with
+// the GPU waiting for it):
+//   'O' 3 depth K | u32 n_points | i32 origin[3] | u32 payload_len | u32 len[K] | part 0 | part 1 | ..
+// The leaves are cut in Morton order between grandparent cells (leaf cell >> 6), so the nodes of the two lowest inner
+// levels of the parts add up to the frame's (the decoder takes the sizes of its stride-16 / stride-32 coordinate sets
+// from them); the levels above are coded once per part that reaches them.  oracle/pcc_oracle.c states the rule.
+//
 // Blob: 'O' ver depth 0 | u32 n_points | i32 origin[3] | u32 payload_len |
 // payload.  Payload = one rANS64 stream (12-bit probabilities, 32-bit words)
 // of the occupancy bytes in breadth-first order (root first, Morton order
@@ -32,6 +40,7 @@ constexpr uint64_t kRansL = 1ull << 31;
 constexpr int kCtxPerClass = 36;
 constexpr int kClasses = 3;
 constexpr int kHeader = 24;
+constexpr int kMaxParts = 16;   // blob version 3: parts a decoder accepts (the encoder writes at most 8)
 
 inline void adapt(uint16_t& p1, int bit) {
   const uint32_t p = p1, up = p + ((kProbOne - p) >> 4), dn = p - (p >> 4);
@@ -82,6 +91,9 @@ inline uint32_t compact3(uint64_t x) {
 }
 
 }  // namespace
+
+static int octree_decode_cells(const uint8_t* h_in, int64_t len, std::vector<uint64_t>* cells, int64_t* h_level_n,
+                               int32_t origin[3]);
 
 extern "C" int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, int depth,
                                int64_t n_points, const int32_t* h_origin, uint8_t* h_out, int64_t cap,
@@ -166,13 +178,15 @@ extern "C" int pcc_octree_pack(const uint8_t* h_occ, const int64_t* h_level_n, i
 
 extern "C" int pcc_octree_peek(const uint8_t* h_in, int64_t len, int64_t* h_n_points, int* h_depth,
                                int32_t* h_origin) {
-  if (!h_in || len < kHeader || h_in[0] != 'O' || (h_in[1] != 1 && h_in[1] != 2) || h_in[2] > 16) {
+  if (!h_in || len < kHeader || h_in[0] != 'O' || h_in[1] < 1 || h_in[1] > 3 || h_in[2] > 16 ||
+      (h_in[1] == 3 && (h_in[3] < 2 || h_in[3] > kMaxParts))) {
     pcc_set_error("pcc_octree_peek: not an octree blob (len=%lld)", (long long)len);
     return PCC_E_STREAM;
   }
   const int64_t n = (int64_t)get_u32(h_in + 4);
   const int64_t payload = (int64_t)get_u32(h_in + 20);
-  if (kHeader + payload > len || (n > 0 && (h_in[2] < 1 || payload < 8))) {
+  if (kHeader + payload > len || (n > 0 && (h_in[2] < 1 || payload < 8)) ||
+      (h_in[1] == 3 && payload < (int64_t)h_in[3] * (4 + kHeader))) {
     pcc_set_error("pcc_octree_peek: truncated blob");
     return PCC_E_STREAM;
   }
@@ -212,6 +226,19 @@ static int octree_decode_cells(const uint8_t* h_in, int64_t len, std::vector<uin
   if (r != PCC_OK) return r;
   cells->clear();
   if (n == 0) return PCC_OK;
+  if (h_in[1] == 3) {   // parts, one after the other here (codec.hip decodes them side by side)
+    int K = 0;
+    const uint8_t* pp[kMaxParts];
+    int64_t pl[kMaxParts];
+    const int rp = pcc_octree_parts(h_in, len, &K, pp, pl);
+    if (rp != PCC_OK) return rp;
+    std::vector<PccOctPart> parts((size_t)K);
+    for (int k = 0; k < K; ++k) {
+      const int rk = pcc_octree_unpack_part(pp[k], pl[k], &parts[(size_t)k]);
+      if (rk != PCC_OK) return rk;
+    }
+    return pcc_octree_merge_parts(h_in, len, parts.data(), K, cells, h_level_n);
+  }
   if (h_in[1] != 1) {   // blob version 2 is coded and decoded by the GPU (octree2.hip): there is no host decoder for it
     pcc_set_error("pcc_octree_unpack: blob version %d needs a context (pcc_octree_decode_ctx / pcc_octree_decode_dev)", h_in[1]);
     return PCC_E_STREAM;
@@ -283,6 +310,144 @@ static int octree_decode_cells(const uint8_t* h_in, int64_t len, std::vector<uin
     return PCC_E_STREAM;
   }
   cells->swap(cur);
+  return PCC_OK;
+}
+
+// ---- blob version 3: the parts of a blob, one part decoded, the decoded parts put together ---------------------------
+// (internal, rans_gate.h: codec.hip runs pcc_octree_unpack_part on its worker threads)
+int pcc_octree_parts(const uint8_t* h_in, int64_t len, int* K, const uint8_t** part, int64_t* part_len) {
+  int64_t n = 0;
+  int depth = 0;
+  int32_t origin[3];
+  const int r = pcc_octree_peek(h_in, len, &n, &depth, origin);
+  if (r != PCC_OK) return r;
+  if (h_in[1] != 3) {
+    *K = 1;
+    part[0] = h_in;
+    part_len[0] = len;
+    return PCC_OK;
+  }
+  const int k_parts = h_in[3];
+  const int64_t payload = (int64_t)get_u32(h_in + 20);
+  int64_t pos = kHeader + 4 * (int64_t)k_parts, sum_n = 0;
+  for (int k = 0; k < k_parts; ++k) {
+    const int64_t pl = (int64_t)get_u32(h_in + kHeader + 4 * k);
+    if (pl < kHeader || pos + pl > kHeader + payload) {
+      pcc_set_error("pcc_octree_unpack: part %d of %d: %lld bytes at %lld of a %lld-byte payload", k, k_parts, (long long)pl,
+                    (long long)(pos - kHeader), (long long)payload);
+      return PCC_E_STREAM;
+    }
+    const uint8_t* pb = h_in + pos;
+    int64_t pn = 0;
+    int pd = 0;
+    int32_t po[3];
+    const int rk = pcc_octree_peek(pb, pl, &pn, &pd, po);
+    if (rk != PCC_OK) return rk;
+    if (pb[1] != 1 || (pn > 0 && (pd != depth || po[0] != origin[0] || po[1] != origin[1] || po[2] != origin[2]))) {
+      pcc_set_error("pcc_octree_unpack: part %d is not a version-1 blob under the frame's root", k);
+      return PCC_E_STREAM;
+    }
+    sum_n += pn;
+    part[k] = pb;
+    part_len[k] = pl;
+    pos += pl;
+  }
+  if (sum_n != n || pos != kHeader + payload) {
+    pcc_set_error("pcc_octree_unpack: parts announce %lld points in %lld bytes, the blob %lld in %lld", (long long)sum_n,
+                  (long long)(pos - kHeader), (long long)n, (long long)payload);
+    return PCC_E_STREAM;
+  }
+  *K = k_parts;
+  return PCC_OK;
+}
+
+int pcc_octree_unpack_part(const uint8_t* h_in, int64_t len, PccOctPart* out) {
+  for (int L = 0; L < 16; ++L) out->level_n[L] = 0;
+  out->cells.clear();
+  if (!h_in || len < kHeader || h_in[1] != 1) {
+    pcc_set_error("pcc_octree_unpack: a part must be a version-1 blob");
+    return PCC_E_STREAM;
+  }
+  int32_t origin[3];
+  return octree_decode_cells(h_in, len, &out->cells, out->level_n, origin);
+}
+
+// parts -> the frame's cells (Morton order) and level counts; a part must begin in a later grandparent cell than the
+// one the part in front of it ends in (only then are the leaves distinct, sorted, and the counts of the two lowest
+// inner levels sums)
+int pcc_octree_merge_parts(const uint8_t* h_in, int64_t len, PccOctPart* parts, int K, std::vector<uint64_t>* cells,
+                           int64_t* h_level_n) {
+  int64_t n = 0;
+  int depth = 0;
+  const int r = pcc_octree_peek(h_in, len, &n, &depth, nullptr);
+  if (r != PCC_OK) return r;
+  int64_t total = 0;
+  bool any = false;
+  uint64_t last = 0;
+  for (int k = 0; k < K; ++k) {
+    const std::vector<uint64_t>& c = parts[k].cells;
+    if (c.empty()) continue;
+    if (any && (c.front() >> 6) <= (last >> 6)) {
+      pcc_set_error("pcc_octree_unpack: part %d begins inside or in front of the cell the part before it ends in", k);
+      return PCC_E_STREAM;
+    }
+    any = true;
+    last = c.back();
+    total += (int64_t)c.size();
+  }
+  if (total != n) {
+    pcc_set_error("pcc_octree_unpack: parts decoded %lld points, header says %lld", (long long)total, (long long)n);
+    return PCC_E_STREAM;
+  }
+  if (h_level_n)
+    for (int L = 0; L < 16; ++L) {
+      h_level_n[L] = 0;
+      for (int k = 0; k < K; ++k)
+        if (!parts[k].cells.empty()) h_level_n[L] += parts[k].level_n[L];
+    }
+  if (K == 1) {
+    cells->swap(parts[0].cells);
+    return PCC_OK;
+  }
+  cells->clear();
+  cells->reserve((size_t)n);
+  for (int k = 0; k < K; ++k) cells->insert(cells->end(), parts[k].cells.begin(), parts[k].cells.end());
+  return PCC_OK;
+}
+
+// cells -> points (internal: codec.hip, straight into its own arrays)
+void pcc_octree_cells_to_points(const uint64_t* cells, int64_t n, const int32_t origin[3], int32_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    out[3 * i] = (int32_t)compact3(cells[i] >> 2) + origin[0];
+    out[3 * i + 1] = (int32_t)compact3(cells[i] >> 1) + origin[1];
+    out[3 * i + 2] = (int32_t)compact3(cells[i]) + origin[2];
+  }
+}
+
+// the envelope of version 3 around K finished parts (version-1 blobs under the frame's root)
+int pcc_octree_join_parts(int depth, const int32_t origin[3], int64_t n_points, const std::vector<uint8_t>* parts, int K,
+                          uint8_t* h_out, int64_t cap, int64_t* h_len) {
+  int64_t total = kHeader + 4 * (int64_t)K;
+  for (int k = 0; k < K; ++k) total += (int64_t)parts[k].size();
+  if (!h_out || !h_len || K < 2 || K > kMaxParts || depth < 1 || depth > 16 || total > cap) {
+    pcc_set_error("pcc_octree_join_parts: bad argument (K=%d, %lld bytes, capacity %lld)", K, (long long)total, (long long)cap);
+    return total > cap ? PCC_E_NOMEM : PCC_E_ARG;
+  }
+  memset(h_out, 0, kHeader);
+  h_out[0] = 'O';
+  h_out[1] = 3;
+  h_out[2] = (uint8_t)depth;
+  h_out[3] = (uint8_t)K;
+  put_u32(h_out + 4, (uint32_t)n_points);
+  for (int a = 0; a < 3; ++a) put_u32(h_out + 8 + 4 * a, (uint32_t)origin[a]);
+  put_u32(h_out + 20, (uint32_t)(total - kHeader));
+  int64_t pos = kHeader + 4 * (int64_t)K;
+  for (int k = 0; k < K; ++k) {
+    put_u32(h_out + kHeader + 4 * k, (uint32_t)parts[k].size());
+    memcpy(h_out + pos, parts[k].data(), parts[k].size());
+    pos += (int64_t)parts[k].size();
+  }
+  *h_len = total;
   return PCC_OK;
 }
 

@@ -52,6 +52,20 @@ int pcc_rans_decode8_gated(const uint8_t* h_in, int64_t len, const uint8_t* h_id
 // octree_host.cpp: pcc_octree_unpack_levels into a vector that is sized by what the stream actually DECODED, not by
 // the point count its header announces (decoders of untrusted containers; h_level_n needs 16 entries).
 int pcc_octree_unpack_vec(const uint8_t* h_in, int64_t len, std::vector<int32_t>* pts, int64_t* h_level_n);
+// octree_host.cpp, blob version 3 (parts coded and decoded side by side): the parts of a blob (K = 1 and the blob itself
+// for versions 1 / 2; arrays of 16), one part decoded, the decoded parts checked against each other and put together
+// (cells = Morton cell indexes relative to the root cube), cells -> points, and the envelope around finished parts
+struct PccOctPart {
+  std::vector<uint64_t> cells;
+  int64_t level_n[16];
+};
+int pcc_octree_parts(const uint8_t* h_in, int64_t len, int* K, const uint8_t** part, int64_t* part_len);
+int pcc_octree_unpack_part(const uint8_t* h_in, int64_t len, PccOctPart* out);
+int pcc_octree_merge_parts(const uint8_t* h_in, int64_t len, PccOctPart* parts, int K, std::vector<uint64_t>* cells,
+                           int64_t* h_level_n);
+void pcc_octree_cells_to_points(const uint64_t* cells, int64_t n, const int32_t origin[3], int32_t* out);
+int pcc_octree_join_parts(int depth, const int32_t origin[3], int64_t n_points, const std::vector<uint8_t>* parts, int K,
+                          uint8_t* h_out, int64_t cap, int64_t* h_len);
 
 // rans_gpu.hip: pcc_rans_encode_dev without its read-back (see there)
 struct pcc_ctx;

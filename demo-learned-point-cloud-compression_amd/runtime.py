@@ -552,6 +552,7 @@ class Runtime:
 
 
 OCTREE_V2_MIN_LEAVES = 65536     # include/pcc.h PCC_OCTREE_V2_MIN_LEAVES
+OCTREE_V3_MIN_LEAVES = 8192      # include/pcc.h PCC_OCTREE_V3_MIN_LEAVES
 
 
 # ---------------------------------------------------------------- GPU coder (container version 1)

@@ -141,7 +141,9 @@ def gpcc_encode_begin(keys_dev, keys_host, lo, hi, key_shift, slot=0):
     n = hi - lo
     if n == 0:
         return lambda: _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
-    if n > _rt.OCTREE_V2_MIN_LEAVES:     # blob version 2: the entropy coder runs on the GPU too, nothing left for the host
+    if n >= _rt.OCTREE_V3_MIN_LEAVES:
+        # blob version 2 (above OCTREE_V2_MIN_LEAVES: the entropy coder runs on the GPU too) or 3 (the leaves in parts
+        # coded side by side): one library call, nothing left for the host
         blob = rt.octree_encode(keys_dev[lo:hi], key_shift)
         return lambda: blob
     first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
@@ -157,12 +159,13 @@ def gpcc_encode(keys_dev, keys_host, lo, hi, key_shift):
     writes an ASCII PLY of `points/8` and shells out to tmc3; here the device
     builds the octree occupancy bytes and the host entropy-codes them — above
     PCC_OCTREE_V2_MIN_LEAVES leaves (BASELINE.json configs[2]: a LiDAR sweep) the GPU
-    entropy-codes them too (blob version 2, csrc/octree2.hip)."""
+    entropy-codes them too (blob version 2, csrc/octree2.hip); from PCC_OCTREE_V3_MIN_LEAVES leaves up to there
+    the leaves go in parts that are coded and decoded side by side (blob version 3, csrc/octree_host.cpp)."""
     rt = _rt.current()
     n = hi - lo
     if n == 0:
         return _rt.octree_pack(np.zeros(0, np.uint8), [], 0, [0, 0, 0])
-    if keys_host is None or n > _rt.OCTREE_V2_MIN_LEAVES:   # one library call (it reads the two end keys itself)
+    if keys_host is None or n >= _rt.OCTREE_V3_MIN_LEAVES:   # one library call (it reads the two end keys itself; versions 2 / 3 by size)
         return rt.octree_encode(keys_dev[lo:hi], key_shift)
     first, last = int(keys_host[lo]) & 0xFFFFFFFFFFFFFFFF, int(keys_host[hi - 1]) & 0xFFFFFFFFFFFFFFFF
     depth, origin = octree_depth_origin(first, last, key_shift)

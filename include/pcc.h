@@ -555,7 +555,17 @@ int pcc_octree_decode(const uint8_t* h_in, int64_t len, int32_t* h_points,
  *   _decode_ctx : points to the host (h_points NULL: only the count)
  *   _decode_dev : points left in HBM (int32 [n,3], Morton order, origin added);
  *                 h_level_n (16 entries, nullable) = nodes per octree level */
+/* Blob version 3 (round 4; csrc/octree_host.cpp gives the layout): the frame's
+ * leaves in K = min(8, n / 4096) parts (at least 2), each a complete version-1
+ * blob under the frame's root cube, cut between grandparent cells — coded by K
+ * workgroups + K host coders and decoded by K host decoders side by side (the
+ * serial decoder of a latent-sized slot stood at the head of every decode with
+ * the GPU waiting for it).  pcc_octree_encode writes it for sets of
+ * PCC_OCTREE_V3_MIN_LEAVES leaves and more, up to PCC_OCTREE_V2_MIN_LEAVES;
+ * every host decoder above reads it (pcc_octree_unpack_levels: levels depth-1
+ * and depth-2 are the frame's, the levels above count a node once per part). */
 #define PCC_OCTREE_V2_MIN_LEAVES 65536
+#define PCC_OCTREE_V3_MIN_LEAVES 8192
 int pcc_octree_encode_version(pcc_ctx* ctx, const uint64_t* d_keys, int64_t n,
                               int key_shift, int version, uint8_t* h_out,
                               int64_t cap, int64_t* h_len);

@@ -48,6 +48,7 @@ class Oracle:
         self.lib.orc_rans_encode.restype = C.c_int64
         self.lib.orc_octree_encode.restype = C.c_int64
         self.lib.orc_octree2_encode.restype = C.c_int64
+        self.lib.orc_octree3_encode.restype = C.c_int64
         self.lib.orc_octree_decode.restype = C.c_int64
         with np.load(ckpt) as f:
             self.t = {k: f[k] for k in f.files}
@@ -289,15 +290,18 @@ class Oracle:
         return sym
 
     OCTREE_V2_MIN_LEAVES = 65536     # include/pcc.h PCC_OCTREE_V2_MIN_LEAVES: larger sets take blob version 2
+    OCTREE_V3_MIN_LEAVES = 8192      # include/pcc.h PCC_OCTREE_V3_MIN_LEAVES: from here up to there, version 3
 
     def octree_encode(self, points, bias, version=None):
-        """version None: the product's rule (blob version 2, the GPU-coded form, above 65536 leaves)"""
+        """version None: the product's rule (blob version 2, the GPU-coded form, above 65536 leaves; version 3, parts
+        coded side by side, from 8192 leaves; version 1 below)"""
         points = np.ascontiguousarray(points, dtype=np.int32)
         if version is None:
-            version = 2 if points.shape[0] > self.OCTREE_V2_MIN_LEAVES else 1
+            n = points.shape[0]
+            version = 2 if n > self.OCTREE_V2_MIN_LEAVES else (3 if n >= self.OCTREE_V3_MIN_LEAVES else 1)
         cap = 1024 + 16 * points.shape[0] * 2 + 64
         out = np.empty(cap, dtype=np.uint8)
-        fn = self.lib.orc_octree2_encode if version == 2 else self.lib.orc_octree_encode
+        fn = {1: self.lib.orc_octree_encode, 2: self.lib.orc_octree2_encode, 3: self.lib.orc_octree3_encode}[version]
         n = fn(_p(points), C.c_int64(points.shape[0]), C.c_int(bias), _p(out), C.c_int64(cap))
         assert n >= 0
         return out[:n].tobytes()

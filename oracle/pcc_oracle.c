@@ -621,12 +621,8 @@ static int cmp_u64(const void* a, const void* b) {
  * cube of the bias-shifted lattice, aligned to its own size, that holds every
  * point (so the global Morton order of the tensor is also the order inside the
  * cube); origin = its corner, depth = log2 of its side. */
-ORC_API int64_t orc_octree_encode(const int32_t* points, int64_t n, int bias, uint8_t* out, int64_t cap) {
-  if (cap < 24) return -1;
-  memset(out, 0, 24);
-  out[0] = 'O'; out[1] = 1;
-  w32(out + 4, (uint32_t)n);
-  if (n == 0) return 24;
+/* Morton keys of the points, sorted, relative to the corner of the root cube; depth and origin of that cube */
+static uint64_t* oct_keys(const int32_t* points, int64_t n, int bias, int* depth_out, int32_t origin[3]) {
   uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
   for (int64_t i = 0; i < n; ++i)
     keys[i] = (part3((uint32_t)(points[3 * i] + bias)) << 2) | (part3((uint32_t)(points[3 * i + 1] + bias)) << 1) |
@@ -639,14 +635,25 @@ ORC_API int64_t orc_octree_encode(const int32_t* points, int64_t n, int bias, ui
     while (diff) { ++msb; diff >>= 1; }
     if (msb >= 0) depth = msb / 3 + 1;
   }
+  const uint64_t corner = (keys[0] >> (3 * depth)) << (3 * depth);
+  origin[0] = (int32_t)unpart3(corner >> 2) - bias;
+  origin[1] = (int32_t)unpart3(corner >> 1) - bias;
+  origin[2] = (int32_t)unpart3(corner) - bias;
+  for (int64_t i = 0; i < n; ++i) keys[i] -= corner;
+  *depth_out = depth;
+  return keys;
+}
+
+/* version-1 blob of the leaves `keys` (sorted, relative to the corner) of a root cube of the given depth and origin —
+ * a frame's leaves, or (blob version 3) one part of them under the FRAME's root; returns the blob length or -1 */
+static int64_t oct_code(const uint64_t* keys, int64_t n, int depth, const int32_t origin[3], uint8_t* out, int64_t cap) {
+  if (cap < 24) return -1;
+  memset(out, 0, 24);
+  out[0] = 'O'; out[1] = 1;
+  w32(out + 4, (uint32_t)n);
+  if (n == 0) return 24;
   out[2] = (uint8_t)depth;
-  {
-    const uint64_t corner = (keys[0] >> (3 * depth)) << (3 * depth);
-    w32(out + 8, (uint32_t)((int32_t)unpart3(corner >> 2) - bias));
-    w32(out + 12, (uint32_t)((int32_t)unpart3(corner >> 1) - bias));
-    w32(out + 16, (uint32_t)((int32_t)unpart3(corner) - bias));
-    for (int64_t i = 0; i < n; ++i) keys[i] -= corner;
-  }
+  for (int a = 0; a < 3; ++a) w32(out + 8 + 4 * a, (uint32_t)origin[a]);
   /* forward modelling, level by level */
   uint16_t model[108];
   for (int i = 0; i < 108; ++i) model[i] = 2048;
@@ -687,10 +694,67 @@ ORC_API int64_t orc_octree_encode(const int32_t* points, int64_t n, int bias, ui
   const int64_t payload = (int64_t)(end - ptr) * 4;
   int64_t ret = -1;
   if (24 + payload <= cap) { w32(out + 20, (uint32_t)payload); memcpy(out + 24, ptr, (size_t)payload); ret = 24 + payload; }
-  free(buf); free(bits); free(probs); free(keys);
+  free(buf); free(bits); free(probs);
   return ret;
 }
 
+ORC_API int64_t orc_octree_encode(const int32_t* points, int64_t n, int bias, uint8_t* out, int64_t cap) {
+  if (cap < 24) return -1;
+  if (n == 0) {
+    const int32_t org0[3] = {0, 0, 0};
+    return oct_code(NULL, 0, 0, org0, out, cap);
+  }
+  int depth;
+  int32_t origin[3];
+  uint64_t* keys = oct_keys(points, n, bias, &depth, origin);
+  const int64_t ret = oct_code(keys, n, depth, origin, out, cap);
+  free(keys);
+  return ret;
+}
+
+/* ---------------------------------------------------- octree, blob version 3 */
+
+/* Blob version 3 of the `points` slot (round 4): the frame's leaves in K parts that are coded — and decoded — side
+ * by side, each a complete version-1 blob under the FRAME's root cube (same depth and origin):
+ *   'O' 3 depth K | u32 n | i32 origin[3] | u32 payload_len | u32 len[K] | part 0 | part 1 | ..
+ * K = min(8, n / 4096), at least 2.  The leaves are cut in Morton order at the first leaf at or behind n k / K whose
+ * grandparent cell (leaf cell >> 6) differs from its predecessor's: a part is a run of whole grandparent cells (an
+ * empty part is a 24-byte blob of zero points), so the nodes of the two lowest inner levels of the parts add up to
+ * the frame's — the decoder takes the sizes of the stride-16 / stride-32 coordinate sets from them —, and the parts'
+ * decoders share nothing.  The upper levels of the frame's tree are coded once per part that reaches them. */
+#define O3_KMAX 8
+#define O3_PER_PART 4096
+static int64_t o3_cut(const uint64_t* keys, int64_t n, int64_t t) {
+  if (t <= 0) return 0;
+  for (int64_t e = t; e < n; ++e)
+    if ((keys[e] >> 6) != (keys[e - 1] >> 6)) return e;
+  return n;
+}
+ORC_API int64_t orc_octree3_encode(const int32_t* points, int64_t n, int bias, uint8_t* out, int64_t cap) {
+  if (n < 2 || cap < 24) return -1;
+  int K = (int)(n / O3_PER_PART);
+  if (K > O3_KMAX) K = O3_KMAX;
+  if (K < 2) K = 2;
+  int depth;
+  int32_t origin[3];
+  uint64_t* keys = oct_keys(points, n, bias, &depth, origin);
+  memset(out, 0, 24);
+  out[0] = 'O'; out[1] = 3; out[2] = (uint8_t)depth; out[3] = (uint8_t)K;
+  w32(out + 4, (uint32_t)n);
+  for (int a = 0; a < 3; ++a) w32(out + 8 + 4 * a, (uint32_t)origin[a]);
+  int64_t pos = 24 + 4 * K, ret = -1;
+  int ok = pos <= cap;
+  for (int k = 0; k < K && ok; ++k) {
+    const int64_t lo = o3_cut(keys, n, n * k / K), hi = k + 1 == K ? n : o3_cut(keys, n, n * (k + 1) / K);
+    const int64_t len = oct_code(keys + lo, hi - lo, depth, origin, out + pos, cap - pos);
+    if (len < 0) { ok = 0; break; }
+    w32(out + 24 + 4 * k, (uint32_t)len);
+    pos += len;
+  }
+  if (ok) { w32(out + 20, (uint32_t)(pos - 24)); ret = pos; }
+  free(keys);
+  return ret;
+}
 
 /* ---------------------------------------------------- octree, blob version 2 */
 
@@ -953,9 +1017,43 @@ static int64_t orc_octree2_decode(const uint8_t* in, int64_t len, int32_t* point
 }
 
 /* returns number of points (Morton order), or -1 */
+ORC_API int64_t orc_octree_decode(const uint8_t* in, int64_t len, int32_t* points, int64_t cap_points);
+/* blob version 3: the parts one after the other; a part must be a version-1 blob under the frame's root, and the first
+ * leaf of a part must lie in a later grandparent cell than the last leaf in front of it */
+static int64_t orc_octree3_decode(const uint8_t* in, int64_t len, int32_t* points, int64_t cap_points) {
+  const int depth = in[2], K = in[3];
+  const int64_t n = (int64_t)r32(in + 4), payload = (int64_t)r32(in + 20);
+  if (K < 2 || K > 16 || 24 + payload > len || payload < 4 * K || n > cap_points) return -1;
+  int32_t org[3];
+  for (int a = 0; a < 3; ++a) org[a] = (int32_t)r32(in + 8 + 4 * a);
+  int64_t pos = 24 + 4 * K, got = 0;
+  uint64_t last_cell = 0;
+  for (int k = 0; k < K; ++k) {
+    const int64_t plen = (int64_t)r32(in + 24 + 4 * k);
+    if (plen < 24 || pos + plen > 24 + payload) return -1;
+    const uint8_t* pb = in + pos;
+    if (pb[0] != 'O' || pb[1] != 1) return -1;
+    const int64_t pn = (int64_t)r32(pb + 4);
+    if (pn > 0) {
+      if (pb[2] != depth || got + pn > n) return -1;
+      for (int a = 0; a < 3; ++a) if ((int32_t)r32(pb + 8 + 4 * a) != org[a]) return -1;
+      if (orc_octree_decode(pb, plen, points + 3 * got, pn) != pn) return -1;
+      const int32_t* f = points + 3 * got;
+      const uint64_t first_cell = (part3((uint32_t)(f[0] - org[0])) << 2) | (part3((uint32_t)(f[1] - org[1])) << 1) | part3((uint32_t)(f[2] - org[2]));
+      if (got > 0 && (first_cell >> 6) <= (last_cell >> 6)) return -1;
+      const int32_t* l = points + 3 * (got + pn - 1);
+      last_cell = (part3((uint32_t)(l[0] - org[0])) << 2) | (part3((uint32_t)(l[1] - org[1])) << 1) | part3((uint32_t)(l[2] - org[2]));
+      got += pn;
+    }
+    pos += plen;
+  }
+  return got == n && pos == 24 + payload ? n : -1;
+}
+
 ORC_API int64_t orc_octree_decode(const uint8_t* in, int64_t len, int32_t* points, int64_t cap_points) {
-  if (len < 24 || in[0] != 'O' || (in[1] != 1 && in[1] != 2)) return -1;
+  if (len < 24 || in[0] != 'O' || (in[1] != 1 && in[1] != 2 && in[1] != 3)) return -1;
   if (in[1] == 2) return orc_octree2_decode(in, len, points, cap_points);
+  if (in[1] == 3) return orc_octree3_decode(in, len, points, cap_points);
   const int depth = in[2];
   const int64_t n = (int64_t)r32(in + 4);
   if (n == 0) return 0;

@@ -164,16 +164,17 @@ def test_single_frame_with_a_latent_beyond_the_small_kernels_equals_oracle(codec
 
 
 def test_gop_mixing_both_blob_versions(codec, wl):
-    """a GOP whose first frame has a latent above 65536 rows (geometry blob version 2, coded and decoded by the GPU) and
-    whose second frame has a small one (version 1, host coder): the slots carry the two versions side by side, and
-    every frame decodes to what it decodes to when coded alone (frames of a GOP do not interact)"""
+    """a GOP whose first frame has a latent above 65536 rows (geometry blob version 2, coded and decoded by the GPU),
+    whose second has one between 8192 and that (version 3, parts coded side by side) and whose third has a small one
+    (version 1, one host coder): the slots carry the three versions side by side, and every frame decodes to what it
+    decodes to when coded alone (frames of a GOP do not interact)"""
     enc, dec = codec
-    big, small = wl.fused_scan(3_000_000, seed=2), wl.sphere_shell(64, 25.2, seed=1, offset=(40, -90, 300))
-    out, _ = enc.compress(wl.gop([dict(big), dict(small)]))
+    big, mid, small = wl.fused_scan(3_000_000, seed=2), wl.room(400_000, seed=3), wl.sphere_shell(64, 25.2, seed=1, offset=(40, -90, 300))
+    out, _ = enc.compress(wl.gop([dict(big), dict(mid), dict(small)]))
     blobs = parse(out[3])[7]
-    assert [b[1] for b in blobs] == [2, 1]
+    assert [b[1] for b in blobs] == [2, 3, 1]
     rec, _ = dec.decompress(out[3])
-    for frame, got in zip((big, small), rec):
+    for frame, got in zip((big, mid, small), rec):
         alone, _ = enc.compress(wl.gop([dict(frame)]))
         want, _ = dec.decompress(alone[3])
         assert np.array_equal(got["points"], want[0]["points"]) and np.array_equal(got["colors"], want[0]["colors"])

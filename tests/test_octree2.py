@@ -240,7 +240,7 @@ def test_hip_v2_sizes(rt, oracle, n, extent, shift):
         assert np.array_equal(dec * stride, oracle.keys_to_coords(keys)[:, 1:]), version
     # the operator picks the version by the leaf count, like the oracle
     blob = utils.gpcc_encode(kd, keys.view(np.int64), 0, len(keys), shift)
-    assert blob[1] == (2 if n > 65536 else 1) and blob == oracle.octree_encode(g, bias)
+    assert blob[1] == (2 if n > 65536 else (3 if n >= 8192 else 1)) and blob == oracle.octree_encode(g, bias)
     assert np.array_equal(utils.gpcc_decode(blob, stride), oracle.keys_to_coords(keys)[:, 1:])
 
 
