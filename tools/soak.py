@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak test: three caller threads share one CompressionPipeline / DecompressionPipeline (3 codec slots each, as the
 reference's services do) and code the same two GOPs over and over; every container and every reconstruction must equal
-the first one.  python tools/soak.py [iterations_per_thread]"""
+the first one.  The first GOP's latent has more than 8192 voxels (geometry blob version 3: parts coded on the codec's
+threads), the second is three small frames (version 1).  python tools/soak.py [iterations_per_thread] [container_version]"""
 import concurrent.futures as cf
 import hashlib
 import importlib
@@ -19,10 +20,11 @@ S = [[1.0, 0.0], [0.0, 1.0], [1, 1]]
 def main():
     import torch
     n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    version = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     pkg = importlib.import_module(PKG)
     wl = importlib.import_module(PKG + ".workloads")
-    gops = [[wl.room(200_000, seed=1)], [wl.body(60000, seed=s) for s in (1, 2, 3)]]
-    enc = pkg.CompressionPipeline(S, device=0, slots=3)
+    gops = [[wl.room(400_000, seed=1)], [wl.body(60000, seed=s) for s in (1, 2, 3)]]
+    enc = pkg.CompressionPipeline(S, device=0, slots=3, container_version=version)
     dec = pkg.DecompressionPipeline(device=0, slots=3)
 
     def once(g):
@@ -45,7 +47,7 @@ def main():
     with cf.ThreadPoolExecutor(3) as ex:
         bad = sum(ex.map(worker, range(3)))
     torch.cuda.synchronize()
-    print(f"soak: {3 * n_it} GOPs on 3 threads, mismatches: {bad}")
+    print(f"soak (container version {version}): {3 * n_it} GOPs on 3 threads, mismatches: {bad}")
     return 1 if bad else 0
 
 
