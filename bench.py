@@ -22,6 +22,7 @@ the gathered bundle.  value = 1M-voxel frames of all ranks / max time over ranks
 """
 import argparse
 import importlib
+import gc
 import json
 import os
 import sys
@@ -367,15 +368,23 @@ def main():
     per_rank = {}   # N > 1: ms per step of every rank, per timed region
 
     def timed(host, enc=enc):
-        fence()
-        t_start = time.perf_counter()
-        e_ms, d_ms, last = [], [], None
-        for _ in range(args.steps):
-            last = step(host, enc)
-            e_ms.append(1e3 * (last[1]["timestamps"]["codec_end"] - last[1]["timestamps"]["codec_start"]))
-            d_ms.append(1e3 * (last[3]["timestamps"]["codec_end"] - last[3]["timestamps"]["codec_start"]))
-        fence()
-        dt = time.perf_counter() - t_start
+        # the interpreter's cyclic garbage collector stays out of the timed steps, as in timeit: with torch imported a
+        # full pass walks ~170k objects (8-13 ms on these hosts, 40-50 in the build container) and used to land in one
+        # step of every timed region — 20 steps of 8.9 ms read as 9.4-9.9 (per-step spread on stderr: max 13 ms)
+        gc.collect()
+        gc.disable()
+        try:
+            fence()
+            t_start = time.perf_counter()
+            e_ms, d_ms, last = [], [], None
+            for _ in range(args.steps):
+                last = step(host, enc)
+                e_ms.append(1e3 * (last[1]["timestamps"]["codec_end"] - last[1]["timestamps"]["codec_start"]))
+                d_ms.append(1e3 * (last[3]["timestamps"]["codec_end"] - last[3]["timestamps"]["codec_start"]))
+            fence()
+            dt = time.perf_counter() - t_start
+        finally:
+            gc.enable()
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
@@ -635,6 +644,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "timing": "K steps one after the other between two fences; the interpreter's cyclic garbage collector is "
+                      "collected before and disabled inside every timed region (timeit's practice)",
             "config": {"workload": workload,
                        "weights": "UNTRAINED: seeded synthetic checkpoint (tools/make_checkpoint.py) — the reference's "
                                   "weights are not in its tree; bpp and PSNR below are those of this checkpoint, not of "
