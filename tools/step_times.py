@@ -21,6 +21,12 @@ def main():
     f = wl.room(1_000_000, seed=0)
     enc, dec = pkg.CompressionPipeline(s, slots=1, container_version=cv), pkg.DecompressionPipeline(slots=1)
     rows = []
+    if os.environ.get("STEP_TIMES_GC") == "0":     # as bench.py's timed regions: collected, then disabled
+        for _ in range(6):
+            out, _ = enc.compress({"frames": [dict(f)], "timestamps": {}})
+            dec.decompress(out[3])
+        gc.collect()
+        gc.disable()
     for i in range(n):
         g0 = gc.get_count()
         t0 = time.perf_counter()
