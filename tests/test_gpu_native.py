@@ -355,6 +355,43 @@ def _blob_offsets(container):
     return out
 
 
+def test_native_decode_survives_a_damaged_version_3_slot(wl, codec):
+    """a frame whose latent takes geometry blob version 3 (parts decoded on the codec's threads): seeded corruptions inside
+    the slot — envelope, length table, part headers, part payloads — give a cloud or a PccError, never a fault or a
+    hang, and the codec decodes the clean container afterwards.  (The device path sizes its stride-16 / stride-32 sets
+    from the parts' level counts: what the parts decoded and the order check must keep those exact.)"""
+    import struct
+    native = pkg("native")
+    coords, feats = _stack([wl.room(400_000, seed=3)])
+    cont, _, _ = codec.encode(coords, feats, 1, [[1, 1]])
+    clean = cont[0]
+    off = _blob_offsets(clean)[0]
+    assert clean[off:off + 2] == b"O\x03"
+    k = clean[off + 3]
+    blob_len = 24 + struct.unpack_from("<I", clean, off + 20)[0]
+    ref = codec.decode(clean)
+    n_ref = ref[0].shape[0]
+    rng = np.random.default_rng(77)
+    outcomes = {"ok": 0, "error": 0}
+    spots = [int(v) for v in rng.integers(0, 24 + 4 * k + 24, 25)] + [int(v) for v in rng.integers(0, blob_len, 45)]
+    for i, rel in enumerate(spots):
+        b = bytearray(clean)
+        b[off + rel] ^= int(rng.integers(1, 256))
+        if i % 9 == 8:      # and a swap of two length entries now and then
+            a0, a1 = off + 24, off + 28
+            b[a0:a0 + 4], b[a1:a1 + 4] = b[a1:a1 + 4], b[a0:a0 + 4]
+        try:
+            c, col, offs, _, _ = codec.decode(bytes(b))
+            assert c.shape[0] == col.shape[0] and offs[-1] == c.shape[0]
+            outcomes["ok"] += 1
+        except native.PccError as e:
+            assert e.code < 0
+            outcomes["error"] += 1
+    assert outcomes["ok"] + outcomes["error"] == len(spots) and outcomes["error"] > 0
+    again = codec.decode(clean)
+    assert again[0].shape[0] == n_ref and bool((again[0] == ref[0]).all())
+
+
 def test_native_decode_refuses_a_moved_octree_origin(wl, codec):
     """every bit of the 12 origin bytes of a geometry blob (octree_host.cpp: bytes 8..19, little-endian int32 x 3):
     a flipped bit either leaves the root cube on its 2^depth grid (the cloud is translated; the decode succeeds with
