@@ -28,7 +28,26 @@ import os
 import sys
 import time
 
-import numpy as np
+
+def _cap_thread_pools():
+    """numpy's BLAS and every OpenMP runtime size their pools by the VISIBLE cores (256 on the GPU boxes) while the
+    cgroup grants 16: one parallel region then spends the whole quota of a scheduling period in a few milliseconds and
+    the kernel freezes every thread of the process until the period ends (cpu.stat: throttled 3.6 s of thread time
+    while the workload was generated).  Pools are capped at the cgroup's share before numpy / torch are imported."""
+    budget = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            budget = max(1, min(budget, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.setdefault(var, str(min(budget, 16)))
+
+
+_cap_thread_pools()
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
