@@ -415,7 +415,8 @@ def main():
         # host) shows here, not in the mean
         log(f"[rank {rank}] per-step ms ({'host' if host else 'hbm'} frames): encode min / median / max "
             f"{min(e_ms):.2f} / {float(np.median(e_ms)):.2f} / {max(e_ms):.2f}, decode "
-            f"{min(d_ms):.2f} / {float(np.median(d_ms)):.2f} / {max(d_ms):.2f}")
+            f"{min(d_ms):.2f} / {float(np.median(d_ms)):.2f} / {max(d_ms):.2f}; every step: "
+            + " ".join(f"{a:.1f}+{b:.1f}" for a, b in zip(e_ms, d_ms)))
         return dt, float(np.mean(e_ms)), float(np.mean(d_ms)), last
 
     # timed region (`value`): K steps of the operator contract, host numpy in / host numpy out.  Only the dominant
