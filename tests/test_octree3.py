@@ -194,3 +194,55 @@ def test_codec_slots_take_version_3(rt, oracle, wl, cv):
     rec, _ = dec.decompress(out[1])
     oref = oracle.decompress(ref[1])
     assert np.array_equal(rec[0]["points"], oref[0]["points"]) and np.array_equal(rec[0]["colors"], oref[0]["colors"])
+
+
+# ------------------------------------------------------------------------------------- committed vectors (all versions)
+GOLDEN_SETS = ["sheet_700", "sheet_9000", "sheet_40000", "block_1728", "one"]
+
+
+def _golden():
+    import os
+    from conftest import ROOT
+    return np.load(os.path.join(ROOT, "tests", "golden", "octree_blobs.npz"))
+
+
+@pytest.mark.parametrize("name", GOLDEN_SETS)
+def test_oracle_and_host_decoder_reproduce_the_committed_blobs(oracle, name):
+    """tests/golden/octree_blobs.npz (tools/make_golden.py --octree-only): the oracle writes the same bytes for every
+    version, picks the same version by the rule, and both decoders — the oracle's and the product's host decoder —
+    give the points back from the committed bytes (version 2 has no host decoder: the product refuses it)"""
+    with _golden() as g:
+        pts = g[f"{name}_points"]
+        for v in (1, 2, 3):
+            key = f"{name}_v{v}"
+            if key not in g:
+                continue
+            blob = g[key].tobytes()
+            assert oracle.octree_encode(pts, 4096, version=v) == blob, (name, v)
+            assert np.array_equal(lex(oracle.octree_decode(blob)), lex(pts))
+            rc, got, _ = product_unpack(blob)
+            if v == 2:
+                assert rc != 0 or pts.shape[0] == 0
+            else:
+                assert rc == 0 and np.array_equal(lex(got), lex(pts))
+        assert oracle.octree_encode(pts, 4096)[1] == int(g[f"{name}_rule"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOLDEN_SETS)
+def test_gpu_coders_reproduce_the_committed_blobs(rt, name):
+    """the product's encoders (host coder, GPU coder, parts) write the committed bytes, its decoders read them"""
+    import torch
+    with _golden() as g:
+        pts = g[f"{name}_points"]
+        coords = np.concatenate([np.zeros((pts.shape[0], 1), np.int32), pts * 8], 1).astype(np.int32)
+        keys = rt.morton_keys(torch.from_numpy(coords).to(rt.device))
+        rt.sort_pairs(keys)
+        for v in (1, 2, 3):
+            key = f"{name}_v{v}"
+            if key not in g:
+                continue
+            blob = g[key].tobytes()
+            assert rt.octree_encode(keys, 9, version=v) == blob, (name, v)
+            assert np.array_equal(lex(rt.octree_decode(blob)), lex(pts))
+        assert rt.octree_encode(keys, 9)[1] == int(g[f"{name}_rule"])

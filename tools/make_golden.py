@@ -119,9 +119,45 @@ def emit_sequence(name, frames, oracle):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
 
 
+def octree_sets():
+    """point sets of the geometry-slot vectors (lattice units, bias 4096 = a stride-8 latent): a wavy sheet at three sizes
+    (below the rule of blob version 3, inside it, at its upper end), a dense block, a single point"""
+    def sheet(n, seed, side):
+        rng = np.random.default_rng(seed)
+        out = np.zeros((0, 3), np.int32)
+        while out.shape[0] < n:
+            x, y = rng.integers(0, side, 2 * n), rng.integers(0, side, 2 * n)
+            z = (side / 4 * (1 + np.sin(x / 17.0) * np.cos(y / 23.0))).astype(np.int64) + rng.integers(0, 3, 2 * n)
+            out = np.unique(np.concatenate([out, np.stack([x, y, z], 1).astype(np.int32) - side // 3]), axis=0)
+        return out[rng.permutation(out.shape[0])[:n]]
+    g = np.stack(np.meshgrid(*[np.arange(12)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.int32) - 5
+    return {"sheet_700": sheet(700, 1, 60), "sheet_9000": sheet(9000, 2, 160), "sheet_40000": sheet(40000, 3, 300),
+            "block_1728": g, "one": np.array([[3, -2, 7]], np.int32)}
+
+
+def emit_octree(oracle):
+    """tests/golden/octree_blobs.npz: per set the points and the blob of every version that takes it (1, 2, 3 — version 3
+    from 2 leaves) plus the version the rule picks"""
+    rec = {}
+    for name, pts in octree_sets().items():
+        rec[f"{name}_points"] = pts
+        for v in (1, 2, 3):
+            if v == 3 and pts.shape[0] < 2:
+                continue
+            rec[f"{name}_v{v}"] = np.frombuffer(oracle.octree_encode(pts, 4096, version=v), dtype=np.uint8)
+        rule = oracle.octree_encode(pts, 4096)
+        rec[f"{name}_rule"] = np.int32(rule[1])
+        print("octree", name, pts.shape[0], "leaves; bytes",
+              {v: int(rec[f"{name}_v{v}"].shape[0]) for v in (1, 2, 3) if f"{name}_v{v}" in rec}, "rule", rule[1])
+    np.savez_compressed(os.path.join(OUT, "octree_blobs.npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     o = Oracle()
+    emit_octree(o)
+    if "--octree-only" in sys.argv:
+        return
     f = wl.sphere_shell()
     f["colors"] = np.rint(f["colors"] * 255).astype(np.uint8).astype(np.float64) / 255.0
     emit("c1_sphere", [f], o)
