@@ -534,7 +534,11 @@ class Oracle:
         xkeys, rgb, offs = self.g_s(yk2, yhat, ks, n_batch)
         coords = self.keys_to_coords(xkeys)
         frames = []
-        for f in range(n_batch):
+        # pack_batches counts the frames from the decoded points: num_frames = np.max(points[:, 0]) + 1
+        # (/root/reference/receiver/decoder/codec_parallel.py:483) — frames without points BEHIND the last frame that
+        # has some are not returned, an empty frame in front of it is (as an empty item)
+        n_out = int(coords[:, 0].max()) + 1 if coords.shape[0] else 0
+        for f in range(n_out):
             c = np.nan_to_num(rgb[offs[f]:offs[f + 1]], nan=0.0)
             c = np.clip(c * 255.0, 0, 255) / 255
             frames.append({"points": coords[offs[f]:offs[f + 1], 1:], "colors": c})

@@ -187,6 +187,26 @@ def test_gop_with_ragged_frames(codec, wl):
     check_roundtrip(codec, wl, frames)
 
 
+def test_gop_with_empty_frames(codec, oracle, wl):
+    """frames without a point inside a GOP: the containers equal the oracle's, an empty frame IN FRONT of the last frame
+    that has points comes back as an empty item, empty frames BEHIND it do not come back at all — pack_batches counts the
+    frames from the decoded points (/root/reference/receiver/decoder/codec_parallel.py:483).  (Found by
+    tools/parity_sweep.py: the oracle used to return the trailing empty frame.)"""
+    enc, dec = codec
+    empty = {"points": np.zeros((0, 3), np.int16), "colors": np.zeros((0, 3), np.float64)}
+    a, b = wl.sphere_shell(40, 15.0, seed=5), wl.body(30_000, seed=2)
+    for frames, n_back in (([a, dict(empty)], 1), ([a, dict(empty), b], 3), ([dict(empty), a, dict(empty), dict(empty)], 2)):
+        ref, _ = oracle.compress([dict(f) for f in frames], SETTINGS)
+        out, _ = enc.compress(wl.gop([dict(f) for f in frames]))
+        assert all(out[q] == ref[q] for q in (1, 2, 3))
+        rec, _ = dec.decompress(out[3])
+        oref = oracle.decompress(ref[3])
+        assert len(rec) == len(oref) == n_back
+        for got, want in zip(rec, oref):
+            assert np.array_equal(got["points"], want["points"]) and np.array_equal(got["colors"], want["colors"])
+        assert [r["points"].shape[0] == 0 for r in rec] == [f["points"].shape[0] == 0 for f in frames[:n_back]]
+
+
 def test_c3_lidar_geometry_only(rt, oracle, wl):
     """KITTI-like sweep, octree occupancy coding of the stride-1 voxels: lossless and equal to the oracle"""
     utils = pkg("utils")
