@@ -56,9 +56,9 @@ def main():
             except Exception as e:   # noqa: BLE001
                 print(f"case {seed0 + c}: empty GOP refused ({type(e).__name__})", flush=True)
             continue
-        for cv in (0, 1):
-            ref, _ = oracle.compress([dict(f) for f in frames], settings, version=cv)
-            enc = pkg.CompressionPipeline(settings, device=0, slots=1, container_version=cv)
+        for cv, seek in ((0, 0), (1, 0), (0, 16)):
+            ref, _ = oracle.compress([dict(f) for f in frames], settings, version=cv, seek_points=seek)
+            enc = pkg.CompressionPipeline(settings, device=0, slots=1, container_version=cv, seek_points=seek)
             dec = pkg.DecompressionPipeline(device=0, slots=1)
             out, _ = enc.compress(wl.gop([dict(f) for f in frames]))
             ok = all(out[q] == ref[q] for q in ref)
@@ -69,10 +69,10 @@ def main():
                                                    for a, b in zip(rec, oref))
             bad += (not ok) + (not ok_dec)
             del enc, dec
-            print(f"case {seed0 + c} v{cv}: frames {[f['points'].shape[0] for f in frames]} Q={len(settings)} "
+            print(f"case {seed0 + c} v{cv}{' +seek' if seek else ''}: frames {[f['points'].shape[0] for f in frames]} Q={len(settings)} "
                   f"containers {'equal' if ok else 'DIFFER'} decode {'equal' if ok_dec else 'DIFFERS'} "
                   f"({time.time() - t0:.0f}s)", flush=True)
-    print(f"parity sweep: {cases} cases x 2 container versions, {bad} mismatches")
+    print(f"parity sweep: {cases} cases x (version 0, version 1, version 0 + 16 seek points), {bad} mismatches")
     return 1 if bad else 0
 
 
