@@ -34,6 +34,7 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 
 #include "conv16.h"
 #include "convup.h"
+#include "convrows16.h"
 #include "convgen.h"
 
 // The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound (252 MB: 108 MB of rule book, 128 MB of output).
@@ -724,10 +725,35 @@ static bool force_wide_rows() {
   }
   return v == 1;
 }
+// Launches below this many rows take k_gconv_rows16 (convrows16.h).  PCC_CONV_ROWS16_MAX in the environment (read once)
+// moves the bound: 0 keeps every launch on k_gconv16 (the cross-check of the two kernels).
+constexpr int64_t kRows16MaxRows = 100000;
+static int64_t rows16_max_rows() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* e = getenv("PCC_CONV_ROWS16_MAX");
+    v = e && e[0] ? (int64_t)atoll(e) : kRows16MaxRows;
+    if (v < 0) v = 0;
+  }
+  return v;
+}
 template <bool HEAD, bool UP, bool PERM, int COUT, bool WIDE>
 static void launch16w(hipStream_t st, const float* d_in, const int32_t* d_nbr, int k_vol, int64_t pitch, int64_t n_out,
                       const float* wsw, const float* d_bias, int relu, float* d_out, const float* hw, const float* hb,
                       float* ho, const float* cw, const float* cb, float* co, uint32_t in_bytes) {
+  if constexpr (!HEAD && !UP && !PERM && !WIDE) {
+    // latent-sized launches on an explicit rule book: 16-row windows without compaction (convrows16.h)
+    if (n_out < rows16_max_rows() && (k_vol == 27 || k_vol == 8)) {
+      const dim3 grid(nblk(n_out, 16), COUT / 32);
+      if (k_vol == 27)
+        hipLaunchKernelGGL((k_gconv_rows16<COUT, 27>), grid, dim3(64), 0, st, d_in, d_nbr, pitch, n_out, wsw, d_bias, relu,
+                           d_out, in_bytes);
+      else
+        hipLaunchKernelGGL((k_gconv_rows16<COUT, 8>), grid, dim3(64), 0, st, d_in, d_nbr, pitch, n_out, wsw, d_bias, relu,
+                           d_out, in_bytes);
+      return;
+    }
+  }
   if (n_out < kSmallLaunchRows)
     hipLaunchKernelGGL((k_gconv16<HEAD, UP, PERM, COUT, 32, WIDE>), dim3((nblk(n_out, 32) + 7) / 8 * 8, COUT / 32), dim3(64), 0,
                        st, d_in, d_nbr, k_vol, pitch, n_out, wsw, d_bias, relu, d_out, hw, hb, ho, cw, cb, co, in_bytes);

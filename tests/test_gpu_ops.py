@@ -606,7 +606,20 @@ def test_conv_wide_row_form_is_bit_exact():
     import sys
     env = dict(os.environ, PCC_CONV_WIDE_ROWS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "conv and not switch and not wide_row and not legacy"], env=env, capture_output=True, text=True, timeout=900)
+                        "-k", "conv and not switch and not wide_row and not legacy and not rows16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
+def test_conv_small_launches_rows16_switch_is_bit_exact():
+    """Launches of under 100 000 rows on an explicit rule book run k_gconv_rows16 (convrows16.h: 16-row windows, no
+    compaction); PCC_CONV_ROWS16_MAX=0 (read once per process) keeps them on k_gconv16's 32-row windows, the form they
+    took before: the convolution tests of this file once more under it, in a child process, against the same oracle
+    results"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PCC_CONV_ROWS16_MAX="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "conv and not switch and not wide_row and not legacy and not rows16"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
 
 

@@ -9,6 +9,7 @@ Cases (rows, how the coordinate set is made):
   cand_true   : generative children of the true stride-2 voxels (what trained weights would keep)
   stride2     : the true stride-2 voxels themselves (analysis-side layer)
   stride1     : the input voxels (analysis-side layer, surface statistics)
+  stride4 / stride8 : the true stride-4 / stride-8 voxels (the small analysis-side layers; not in the default list)
 Prints ms per launch, active pairs and useful TFLOP/s for the plain and the fused-head entry point.
 """
 import argparse
@@ -50,7 +51,8 @@ def main():
         keep = torch.sort(torch.randperm(cand2.n, generator=g)[:cs2.n]).values.to(torch.int32).cuda()
         pruned2 = cand2.subset(keep)
         sets = {"cand_pruned": lambda: pruned2.up(), "cand_true": lambda: cs2.up(),
-                "stride2": lambda: cs2, "stride1": lambda: cs1}
+                "stride2": lambda: cs2, "stride1": lambda: cs1,
+                "stride4": lambda: cs4, "stride8": lambda: cs4.down()[0]}
         gw = torch.Generator(device="cuda").manual_seed(1)
         w = (torch.randn((27, 32, 32), generator=gw, device="cuda") * 0.05).contiguous()
         b = torch.randn((32,), generator=gw, device="cuda").contiguous()
@@ -63,6 +65,11 @@ def main():
             x = torch.randn((cs.n, 32), generator=gw, device="cuda").contiguous()
             fns = [("conv", lambda: rt.sparse_conv(x, nbr, w, b, True)),
                    ("conv+head", lambda: rt.sparse_conv_head(x, nbr, w, b, True, hw, hb))]
+            if name in ("stride4", "stride8"):
+                # the latent-sized layers of g_a / h_a / h_s: launches of one partial round of waves
+                w64 = (torch.randn((27, 32, 64), generator=gw, device="cuda") * 0.05).contiguous()
+                b64 = torch.randn((64,), generator=gw, device="cuda").contiguous()
+                fns = [("conv", fns[0][1]), ("conv32x64", lambda: rt.sparse_conv(x, nbr, w64, b64, True))]
             if name == "cand_pruned":
                 # the form the native decoder runs: the candidates' rule book formed in-kernel from the parents' book
                 pn = pruned2.nbr27()
