@@ -725,14 +725,17 @@ static bool force_wide_rows() {
   }
   return v == 1;
 }
-// Launches below this many rows take k_gconv_rows16 (convrows16.h).  PCC_CONV_ROWS16_MAX in the environment (read once)
-// moves the bound: 0 keeps every launch on k_gconv16 (the cross-check of the two kernels).
-constexpr int64_t kRows16MaxRows = 100000;
-static int64_t rows16_max_rows() {
+// Launches of at most this many 16-row windows x column halves — one wave each: two per SIMD — take k_gconv_rows16
+// (convrows16.h); above it the chip is filled and k_gconv16's compaction wins (tools/bench_small_conv.py, one box, k_gconv16
+// -> k_gconv_rows16: 1.6k / 6.6k rows 3^3 24 -> 14 us, 26k rows 2^3 15.0 -> 11.9, 3^3 32 -> 32 25 -> 25 alone and 32.1 ->
+// 26.5 in the step, 3^3 32 -> 64 (3 300 waves) 35.5 -> 46.8: stays on k_gconv16).  PCC_CONV_ROWS16_MAX in the environment
+// (read once) moves the bound: 0 keeps every launch on k_gconv16 (the cross-check of the two kernels).
+constexpr int64_t kRows16MaxWaves = 2048;
+static int64_t rows16_max_waves() {
   static int64_t v = -1;
   if (v < 0) {
     const char* e = getenv("PCC_CONV_ROWS16_MAX");
-    v = e && e[0] ? (int64_t)atoll(e) : kRows16MaxRows;
+    v = e && e[0] ? (int64_t)atoll(e) : kRows16MaxWaves;
     if (v < 0) v = 0;
   }
   return v;
@@ -743,7 +746,7 @@ static void launch16w(hipStream_t st, const float* d_in, const int32_t* d_nbr, i
                       float* ho, const float* cw, const float* cb, float* co, uint32_t in_bytes) {
   if constexpr (!HEAD && !UP && !PERM && !WIDE) {
     // latent-sized launches on an explicit rule book: 16-row windows without compaction (convrows16.h)
-    if (n_out < rows16_max_rows() && (k_vol == 27 || k_vol == 8)) {
+    if ((int64_t)nblk(n_out, 16) * (COUT / 32) <= rows16_max_waves() && (k_vol == 27 || k_vol == 8)) {
       const dim3 grid(nblk(n_out, 16), COUT / 32);
       if (k_vol == 27)
         hipLaunchKernelGGL((k_gconv_rows16<COUT, 27>), grid, dim3(64), 0, st, d_in, d_nbr, pitch, n_out, wsw, d_bias, relu,

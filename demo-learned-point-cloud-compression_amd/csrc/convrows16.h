@@ -2,23 +2,25 @@
 // 354; codec_parallel.py:302-303) on an explicit rule book: launches of under one round of waves (included by conv.hip
 // after conv16.h, whose operand order of the weights it shares).
 //
-// A launch of a few thousand 32-row windows of k_gconv16 lasts as long as ONE window: 27 dependent steps, each a ballot,
-// a compaction through LDS, a record read, a gather and an accumulator round trip — 1.3 .. 1.7 us per step with nobody to
-// hide behind (26.6k rows: 29 .. 34 us for 32 -> 32, 41 .. 45 us for 32 -> 64; the matrix work is 3 us).  Such a launch
-// is bound by the length of that chain, not by anything it moves or multiplies.  Here the chain is cut to the matrix
-// work itself:
+// A launch of a few hundred to a few thousand 32-row windows of k_gconv16 lasts as long as ONE window: k_vol dependent
+// steps, each a ballot, a compaction through LDS, a record read, a gather and an accumulator round trip — 0.9 us per step
+// with nobody to hide behind (1.6k and 6.6k rows, 3^3: 24 us; 26k rows: 25 us alone, 32 in the step).  Such a launch is
+// bound by the length of that chain, not by anything it moves or multiplies.  Here the chain is cut to the matrix work:
 //
 //   * a window is 16 rows = one item: slot n IS row row0 + n, whether or not it has the offset.  No ballot, no compaction,
 //     no slot records, no LDS at all; the accumulators (two 16 x 16 tiles) stay in registers for the whole window;
 //   * a row that lacks offset k gathers from beyond the buffer (zeros, no fetch) and keeps its accumulator by a select
 //     behind the item's chains: its chain sees exactly the PRESENT neighbours, k ascending (include/pcc.h) — fmaf(0, w,
-//     acc) would not do: it turns an accumulator of -0 into +0;
+//     acc) would not do: it turns an accumulator of -0 into +0, and 0 x inf into a NaN;
 //   * all k_vol neighbour indices of a row are requested up front, the offsets are unrolled, D gathers and WD weight
 //     blocks are in flight ahead of the offset being contracted: nothing a step needs was requested in that step.
 //
 // The matrix pipe runs every offset on 16 slots (fill = pairs per row / k_vol, 0.3 .. 0.5 on these levels): 16 MFMAs per
-// window and offset, 26.6k rows x 27 offsets = 23 M cycles over 1024 SIMDs = 11 us — which is why this form is for
-// launches the chip is not filled by (kRows16MaxRows in conv.hip), and k_gconv16's compaction for the others.
+// window and offset — 26k rows x 27 offsets = 23 M cycles over 1024 SIMDs = 11 us.  Measured (tools/bench_small_conv.py, one
+// box, k_gconv16 -> this kernel; the figures include ~8 us of the caller per launch): 1.6k / 6.6k rows 3^3 24 -> 14 us,
+// 2^3 12.5 -> 11.3; 26k rows 2^3 15.0 -> 11.9, 3^3 32 -> 32 25 -> 25 (32.1 -> 26.5 inside the step), 3^3 32 -> 64 — 3 300
+// waves, more than the chip takes at once — 35.5 -> 46.8.  So this form serves launches of at most one wave per SIMD pair
+// (kRows16MaxWaves in conv.hip), and k_gconv16's compaction the others.
 #pragma once
 
 // B operands of a slot in MFMA order from the two 16-B pieces lane (n, q) holds of its row (channels 8q .. 8q+7):

@@ -344,6 +344,39 @@ def test_sparse_conv_down_bit_exact(rt, oracle, clouds, cin, cout, name):
         assert np.array_equal(host(out), oracle.sparse_conv(x, nbr8, w, b, relu))
 
 
+@pytest.mark.parametrize("k_vol", [27, 8])
+@pytest.mark.parametrize("cout", [32, 64])
+def test_conv_rows16_window_edges_and_signed_zero(rt, oracle, k_vol, cout):
+    """k_gconv_rows16 (convrows16.h: launches of at most 2048 sixteen-row windows x column halves) on synthetic rule books:
+    row counts around a window (1, 15, 16, 17), a ragged last window, the bound itself and one launch past it (k_gconv16),
+    rows without any neighbour, whole offsets nobody has, and the two cases a zero operand instead of the select would get
+    wrong: a bias of -0.0 on a row that lacks an offset (its accumulator must stay -0.0), and an infinite weight at an
+    offset some rows lack (they must not turn into NaN)"""
+    rng = np.random.default_rng(1000 * k_vol + cout)
+    bound = 2048 * 16 // (cout // 32)
+    for n_out in (1, 15, 16, 17, 1000, bound - 5, bound, bound + 1):
+        n_in = max(n_out // 2, 3)
+        nbr = rng.integers(0, n_in, size=(k_vol, n_out)).astype(np.int32)
+        nbr[rng.random((k_vol, n_out)) < 0.6] = -1
+        nbr[:, rng.random(n_out) < 0.1] = -1          # rows without a neighbour
+        nbr[k_vol // 2, :] = -1                        # an offset nobody has
+        x = rng.normal(size=(n_in, 32)).astype(np.float32)
+        w, b = _weights(rng, k_vol, 32, cout)
+        b[::3] = -0.0
+        w[1, 5, 7] = np.inf                            # offset 1 only: rows that lack it stay finite
+        for relu in (False, True):
+            out = host(rt.sparse_conv(dev(rt, x), dev(rt, nbr), dev(rt, w), dev(rt, b), relu))
+            ref = oracle.sparse_conv(x, nbr, w, b, relu)
+            nan = np.isnan(ref)                         # inf - inf: a NaN on both sides, whatever its payload
+            assert np.array_equal(np.isnan(out), nan), (n_out, relu)
+            assert np.array_equal(out.view(np.uint32)[~nan], ref.view(np.uint32)[~nan]), (n_out, relu)   # bits: -0.0 != +0.0 here
+            if not relu:
+                lacks = nbr[1] < 0
+                assert np.isfinite(out[lacks]).all() and (n_out < 100 or not np.isfinite(out[~lacks]).all())
+                lone = np.flatnonzero((nbr < 0).all(axis=0))
+                assert (out[lone].view(np.uint32)[:, ::3] == 0x80000000).all()     # the bias of -0.0, untouched
+
+
 def test_conv_linearity(rt, oracle, clouds):
     """size-independent property: conv(a*x) == a*conv(x) for a power of two, zero bias"""
     rng = np.random.default_rng(12)
@@ -611,7 +644,7 @@ def test_conv_wide_row_form_is_bit_exact():
 
 
 def test_conv_small_launches_rows16_switch_is_bit_exact():
-    """Launches of under 100 000 rows on an explicit rule book run k_gconv_rows16 (convrows16.h: 16-row windows, no
+    """Launches of at most 2048 waves on an explicit rule book run k_gconv_rows16 (convrows16.h: 16-row windows, no
     compaction); PCC_CONV_ROWS16_MAX=0 (read once per process) keeps them on k_gconv16's 32-row windows, the form they
     took before: the convolution tests of this file once more under it, in a child process, against the same oracle
     results"""
