@@ -725,11 +725,12 @@ static bool force_wide_rows() {
   }
   return v == 1;
 }
-// Launches of at most this many 16-row windows x column halves — one wave each: two per SIMD — take k_gconv_rows16
-// (convrows16.h); above it the chip is filled and k_gconv16's compaction wins (tools/bench_small_conv.py, one box, k_gconv16
-// -> k_gconv_rows16: 1.6k / 6.6k rows 3^3 24 -> 14 us, 26k rows 2^3 15.0 -> 11.9, 3^3 32 -> 32 25 -> 25 alone and 32.1 ->
-// 26.5 in the step, 3^3 32 -> 64 (3 300 waves) 35.5 -> 46.8: stays on k_gconv16).  PCC_CONV_ROWS16_MAX in the environment
-// (read once) moves the bound: 0 keeps every launch on k_gconv16 (the cross-check of the two kernels).
+// Launches of at most this many 16-row windows (half as many for 32 -> 64, whose waves carry twice the matrix work) take
+// k_gconv_rows16 (convrows16.h); above it the chip is filled and k_gconv16's compaction wins (tools/bench_small_conv.py, one
+// box, k_gconv16 -> k_gconv_rows16: 1.6k / 6.6k rows 3^3 32 -> 32 24 -> 14 us, 32 -> 64 24 -> 22; 26k rows 2^3 15.0 -> 11.9,
+// 3^3 32 -> 32 25 -> 25 alone and 33.3 -> 26.4 in the step, 3^3 32 -> 64 35.5 -> 41.8 alone and 45.6 -> 47.5 in the step:
+// stays on k_gconv16).  PCC_CONV_ROWS16_MAX in the environment (read once) moves the bound: 0 keeps every launch on
+// k_gconv16 (the cross-check of the two kernels).
 constexpr int64_t kRows16MaxWaves = 2048;
 static int64_t rows16_max_waves() {
   static int64_t v = -1;
@@ -747,7 +748,7 @@ static void launch16w(hipStream_t st, const float* d_in, const int32_t* d_nbr, i
   if constexpr (!HEAD && !UP && !PERM && !WIDE) {
     // latent-sized launches on an explicit rule book: 16-row windows without compaction (convrows16.h)
     if ((int64_t)nblk(n_out, 16) * (COUT / 32) <= rows16_max_waves() && (k_vol == 27 || k_vol == 8)) {
-      const dim3 grid(nblk(n_out, 16), COUT / 32);
+      const dim3 grid(nblk(n_out, 16));
       if (k_vol == 27)
         hipLaunchKernelGGL((k_gconv_rows16<COUT, 27>), grid, dim3(64), 0, st, d_in, d_nbr, pitch, n_out, wsw, d_bias, relu,
                            d_out, in_bytes);

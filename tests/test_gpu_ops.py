@@ -347,7 +347,7 @@ def test_sparse_conv_down_bit_exact(rt, oracle, clouds, cin, cout, name):
 @pytest.mark.parametrize("k_vol", [27, 8])
 @pytest.mark.parametrize("cout", [32, 64])
 def test_conv_rows16_window_edges_and_signed_zero(rt, oracle, k_vol, cout):
-    """k_gconv_rows16 (convrows16.h: launches of at most 2048 sixteen-row windows x column halves) on synthetic rule books:
+    """k_gconv_rows16 (convrows16.h: launches of at most 2048 sixteen-row windows, 1024 for 32 -> 64) on synthetic rule books:
     row counts around a window (1, 15, 16, 17), a ragged last window, the bound itself and one launch past it (k_gconv16),
     rows without any neighbour, whole offsets nobody has, and the two cases a zero operand instead of the select would get
     wrong: a bias of -0.0 on a row that lacks an offset (its accumulator must stay -0.0), and an infinite weight at an
