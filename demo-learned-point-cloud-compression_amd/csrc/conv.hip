@@ -34,7 +34,6 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 
 #include "conv16.h"
 #include "convup.h"
-#include "convrows16.h"
 #include "convgen.h"
 
 // The 4 -> 32 input layer (1M rows, 16-B feature rows): HBM-bound (252 MB: 108 MB of rule book, 128 MB of output).
@@ -725,6 +724,10 @@ static bool force_wide_rows() {
   }
   return v == 1;
 }
+// convrows16.hip
+void pcc_rows16_launch(hipStream_t st, int cout, int k_vol, unsigned n_windows, const float* d_in, const int32_t* d_nbr,
+                       int64_t pitch, int64_t n_out, const float* wsw, const float* d_bias, int relu, float* d_out,
+                       uint32_t in_bytes);
 // Launches of at most this many 16-row windows (half as many for 32 -> 64, whose waves carry twice the matrix work) take
 // k_gconv_rows16 (convrows16.h); above it the chip is filled and k_gconv16's compaction wins (tools/bench_small_conv.py, one
 // box, k_gconv16 -> k_gconv_rows16: 1.6k / 6.6k rows 3^3 32 -> 32 24 -> 14 us, 32 -> 64 24 -> 22; 26k rows 2^3 15.0 -> 11.9,
@@ -748,13 +751,7 @@ static void launch16w(hipStream_t st, const float* d_in, const int32_t* d_nbr, i
   if constexpr (!HEAD && !UP && !PERM && !WIDE) {
     // latent-sized launches on an explicit rule book: 16-row windows without compaction (convrows16.h)
     if ((int64_t)nblk(n_out, 16) * (COUT / 32) <= rows16_max_waves() && (k_vol == 27 || k_vol == 8)) {
-      const dim3 grid(nblk(n_out, 16));
-      if (k_vol == 27)
-        hipLaunchKernelGGL((k_gconv_rows16<COUT, 27>), grid, dim3(64), 0, st, d_in, d_nbr, pitch, n_out, wsw, d_bias, relu,
-                           d_out, in_bytes);
-      else
-        hipLaunchKernelGGL((k_gconv_rows16<COUT, 8>), grid, dim3(64), 0, st, d_in, d_nbr, pitch, n_out, wsw, d_bias, relu,
-                           d_out, in_bytes);
+      pcc_rows16_launch(st, COUT, k_vol, nblk(n_out, 16), d_in, d_nbr, pitch, n_out, wsw, d_bias, relu, d_out, in_bytes);
       return;
     }
   }

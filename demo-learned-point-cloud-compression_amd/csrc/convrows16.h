@@ -1,6 +1,6 @@
 // convrows16.h — the latent-sized 32 -> 32 / 32 -> 64 gather-convolutions of g_a, h_a and h_s (codec_pipeline.py:273,287,
-// 354; codec_parallel.py:302-303) on an explicit rule book: launches of under one round of waves (included by conv.hip
-// after conv16.h, whose operand order of the weights it shares).
+// 354; codec_parallel.py:302-303) on an explicit rule book: launches of under one round of waves (included by
+// convrows16.hip; the weights come in conv16.h's operand order).
 //
 // A launch of a few hundred to a few thousand 32-row windows of k_gconv16 lasts as long as ONE window: k_vol dependent
 // steps, each a ballot, a compaction through LDS, a record read, a gather and an accumulator round trip — 0.9 us per step
@@ -22,6 +22,9 @@
 // (46.8 with a wave per column half).  So this form serves launches of at most two waves per SIMD — one for 32 -> 64 —
 // (kRows16MaxWaves in conv.hip), and k_gconv16's compaction the others.
 #pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // B operands of a slot in MFMA order from the two 16-B pieces lane (n, q) holds of its row (channels 8q .. 8q+7):
 // transposes of the 4 x 4 blocks among the four q-lanes (conv16.h, PERM = false)
