@@ -9,6 +9,6 @@ name=$1; shift
 mkdir -p "$ROOT/tools/ab" /tmp/ab_$name
 make -s -j8 -C "$CS"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@" -c "$CS/conv.hip" -o /tmp/ab_$name/conv.o
-objs=$(ls $BD/*.o | grep -v '/conv.o')
+objs=$(ls $BD/*.o | grep -v '/conv\.o$')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/ab/$name.so" $objs /tmp/ab_$name/conv.o -lpthread
 echo "built tools/ab/$name.so"
