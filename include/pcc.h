@@ -229,7 +229,10 @@ int pcc_sparse_conv(pcc_ctx* ctx, const float* d_in, int64_t n_in,
                     int cin, int cout, int relu, float* d_out);
 /* Diagnostic: name of the kernel pcc_sparse_conv (op 0), the siblings-first conv of
  * pcc_sparse_conv_head's generic form (op 1) or pcc_convT_gen (op 2) runs for a
- * shape with 16-byte aligned tensors: "k_gconv16" (32 -> 32 / 64), "k_gconv_gen"
+ * shape with 16-byte aligned tensors: "k_gconv16" (32 -> 32 / 64; the name stands for
+ * the family: op 0 launches of at most 2048 sixteen-row windows, 1024 for 32 -> 64, run
+ * its no-compaction form k_gconv_rows16 — the name does not depend on the row count),
+ * "k_gconv_gen"
  * (any widths that are multiples of 16: C_in <= 128, C_out <= 256), "k_gconv_first"
  * (4 -> multiples of 16), "k_convT16" (the up stage 32 -> 32), "k_convT_mfma" (other
  * multiples of 16 up to 128) — all on the
