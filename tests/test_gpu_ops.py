@@ -100,6 +100,24 @@ def test_sort_pairs_multi_kernel_path(rt, oracle, case):
     assert np.array_equal(u64(k), keys[ref])
 
 
+@pytest.mark.parametrize("n", [65537, 66000, 100_003, 131072, 131073])
+@pytest.mark.parametrize("signed", [False, True])
+def test_sort_pairs_just_above_the_single_workgroup_limit(rt, n, signed):
+    """sorts of 65 537 .. 131 073 keys: the multi-kernel radix passes on few wave tiles — a last workgroup with one live
+    wave (66 000 keys = 65 tiles), 128 and 129 tiles; stable, signed and unsigned.  (A form of these passes in which the
+    scatter kernel scans the raw digit counts itself — two launches per pass instead of four — passed this test and was
+    slower: 185 against 142 us for 95k keys)"""
+    rng = np.random.default_rng(n + int(signed))
+    keys = rng.integers(-(1 << 46), 1 << 46, n, dtype=np.int64) if signed else rng.integers(0, 1 << 47, n, dtype=np.int64)
+    keys[::5] = keys[3]                                 # repeated keys: stability
+    keys[1::2] &= ~np.int64(0xFF00)                     # a digit with few distinct values
+    k = dev(rt, keys.copy())
+    perm = rt.sort_pairs(k, signed=signed)
+    ref = np.argsort(keys if signed else keys.view(np.uint64), kind="stable")
+    assert np.array_equal(host(perm).view(np.uint32), ref.astype(np.uint32))
+    assert np.array_equal(host(k), keys[ref])
+
+
 def test_sort_pairs_signed(rt):
     rng = np.random.default_rng(3)
     keys = rng.integers(-(1 << 62), 1 << 62, 5000, dtype=np.int64)
